@@ -1,0 +1,3 @@
+"""MI355X-native early-exit Conformer encoder (drop-in for the reference's
+``models.model.early_exit.Early_conformer`` / ``full_conformer`` encoder path)."""
+__version__ = "0.1.0"

@@ -1,0 +1,95 @@
+"""ctypes binding of libeec.so (include/eec.h).  There is no CPU fallback: if the
+library is missing, loading raises and every product entry point fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import LIB_PATH
+
+PREC_F16X3, PREC_MIXED, PREC_F16 = 0, 1, 2
+PRECISIONS = {"f16x3": PREC_F16X3, "mixed": PREC_MIXED, "f16": PREC_F16}
+
+_LAYER_FIELDS = [
+    "ffn1_ln_w", "ffn1_ln_b", "ffn1_w1", "ffn1_b1", "ffn1_w2", "ffn1_b2",
+    "attn_ln_w", "attn_ln_b", "attn_in_w", "attn_in_b", "attn_out_w", "attn_out_b",
+    "conv_ln_w", "conv_ln_b", "conv_pw1_w", "conv_pw1_b", "conv_dw_w", "conv_dw_b",
+    "conv_bn_w", "conv_bn_b", "conv_bn_rm", "conv_bn_rv", "conv_pw2_w", "conv_pw2_b",
+    "ffn2_ln_w", "ffn2_ln_b", "ffn2_w1", "ffn2_b1", "ffn2_w2", "ffn2_b2",
+    "final_ln_w", "final_ln_b",
+]
+
+# state_dict key suffix (inside conformer.{e}.conformer_layers.{l}.) of every eec_layer_params field
+LAYER_KEYS = {
+    "ffn1_ln_w": "ffn1.sequential.0.weight", "ffn1_ln_b": "ffn1.sequential.0.bias",
+    "ffn1_w1": "ffn1.sequential.1.weight", "ffn1_b1": "ffn1.sequential.1.bias",
+    "ffn1_w2": "ffn1.sequential.4.weight", "ffn1_b2": "ffn1.sequential.4.bias",
+    "attn_ln_w": "self_attn_layer_norm.weight", "attn_ln_b": "self_attn_layer_norm.bias",
+    "attn_in_w": "self_attn.in_proj_weight", "attn_in_b": "self_attn.in_proj_bias",
+    "attn_out_w": "self_attn.out_proj.weight", "attn_out_b": "self_attn.out_proj.bias",
+    "conv_ln_w": "conv_module.layer_norm.weight", "conv_ln_b": "conv_module.layer_norm.bias",
+    "conv_pw1_w": "conv_module.sequential.0.weight", "conv_pw1_b": "conv_module.sequential.0.bias",
+    "conv_dw_w": "conv_module.sequential.2.weight", "conv_dw_b": "conv_module.sequential.2.bias",
+    "conv_bn_w": "conv_module.sequential.3.weight", "conv_bn_b": "conv_module.sequential.3.bias",
+    "conv_bn_rm": "conv_module.sequential.3.running_mean", "conv_bn_rv": "conv_module.sequential.3.running_var",
+    "conv_pw2_w": "conv_module.sequential.5.weight", "conv_pw2_b": "conv_module.sequential.5.bias",
+    "ffn2_ln_w": "ffn2.sequential.0.weight", "ffn2_ln_b": "ffn2.sequential.0.bias",
+    "ffn2_w1": "ffn2.sequential.1.weight", "ffn2_b1": "ffn2.sequential.1.bias",
+    "ffn2_w2": "ffn2.sequential.4.weight", "ffn2_b2": "ffn2.sequential.4.bias",
+    "final_ln_w": "final_layer_norm.weight", "final_ln_b": "final_layer_norm.bias",
+}
+
+
+class EecConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "d_ff", "dw_kernel", "n_exits",
+                                         "layers_per_exit", "n_mels", "vocab", "max_len")]
+
+
+class EecLayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _LAYER_FIELDS]
+
+
+class EecParams(C.Structure):
+    _fields_ = [("sub0_w", C.c_void_p), ("sub0_b", C.c_void_p), ("sub1_w", C.c_void_p), ("sub1_b", C.c_void_p),
+                ("pe", C.c_void_p), ("layers", C.POINTER(EecLayerParams)),
+                ("head_w", C.POINTER(C.c_void_p)), ("head_b", C.POINTER(C.c_void_p))]
+
+
+EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
+           "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc"]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen libeec.so and declare the prototypes; raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP library is not built. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or early_exit_transformer_amd.build.build_library()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.eec_last_error.restype = C.c_char_p
+    lib.eec_abi_version.restype = C.c_int
+    lib.eec_out_frames.argtypes = [C.c_int]
+    lib.eec_encoder_create.argtypes = [C.POINTER(EecConfig), C.POINTER(C.c_void_p)]
+    lib.eec_encoder_destroy.argtypes = [C.c_void_p]
+    lib.eec_encoder_destroy.restype = None
+    lib.eec_encoder_pack.argtypes = [C.c_void_p, C.POINTER(EecParams), C.c_void_p]
+    lib.eec_encoder_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.eec_encoder_workspace_bytes.restype = C.c_size_t
+    lib.eec_encoder_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+    lib.eec_greedy_ctc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().eec_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

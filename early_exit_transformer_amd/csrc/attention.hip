@@ -1,0 +1,162 @@
+// Key-padding-masked multi-head self-attention core (torch
+// nn.MultiheadAttention -> scaled_dot_product_attention with key_padding_mask):
+//     O[b, t, h*dh + d] = sum_k softmax_k( q[t].k[k] / sqrt(dh) | k < len[b] ) * v[k][d]
+// Only keys are masked; padded query rows are computed like any other (reference behaviour).
+//
+// Workgroup = one (utterance, head, 128-query block); wave = 32 queries.  Both products
+// keep the query on the MFMA lane:
+//     S^T[key][q] = K . Q^T            (A = K fragment from LDS, B = Q fragment in registers)
+//     O^T[d][q]  += V^T . P^T          (A = V^T fragment from LDS, B = P straight from the
+//                                       S^T accumulators, no LDS round trip)
+// so every softmax statistic (running max, sum, rescale) is a per-lane scalar.  The k order
+// of an accumulator-fed operand is permuted (rows 8a+4h+c <-> element 4a+c of half h); the
+// QKV kernel stores V^T with that permutation already applied (vt_perm in linear.hip).
+// Q arrives pre-multiplied by log2(e)/sqrt(dh): probabilities are exp2(s - m).
+// fp16 operands, fp32 accumulate/statistics, online softmax over 32-key tiles so T' is unbounded.
+#include "eec_kernels.h"
+
+namespace eec {
+
+constexpr int kKC = 256;  // keys staged in LDS per chunk
+constexpr float kNegBig = -1.0e30f;
+
+template <int DH>
+struct AttnLds {
+  static constexpr int KLD = (DH + 8) * 2;
+  static constexpr int VLD = (kKC + 8) * 2;
+  static constexpr int KBYTES = kKC * KLD;
+  static constexpr int VBYTES = DH * VLD;
+  static constexpr int TOTAL = KBYTES + VBYTES;
+};
+
+template <int DH, int NP>
+__global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
+  using L = AttnLds<DH>;
+  constexpr int KSQ = DH / 16;  // k-steps of the score product
+  constexpr int DT = DH / 32;   // 32-row tiles of O^T
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_k = smem;
+  char* lds_v = smem + L::KBYTES;
+  const int lane = lane_id(), w = wave_id();
+  const int r = lane & 31, hh = lane >> 5;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int bh = b * a.H + hd;
+  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const bool active = q0 < a.Tq;  // wave-uniform
+  const int len = min(a.enc_len[b], a.Tq);
+
+  h8 qf[KSQ];
+  if (active) {
+    const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + r) * DH + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) qf[ks] = *(const h8*)(qp + ks * 16);
+  }
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = kNegBig, l_run = 0.f;
+
+  const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
+  const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
+  for (int kc0 = 0; kc0 < len; kc0 += kKC) {
+    if (kc0) __syncthreads();
+    // stage K rows [kc0, kc0+KC) and V^T columns of the same keys; zero beyond Tp
+    {
+      constexpr int KP = DH / 8;  // 16-byte pieces per K row
+      for (int p = threadIdx.x; p < kKC * KP; p += kThreads) {
+        const int row = p / KP, c = p % KP;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kc0 + row < a.Tp) v = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
+        *(uint4*)(lds_k + row * L::KLD + c * 16) = v;
+      }
+      constexpr int VP = kKC / 8;
+      for (int p = threadIdx.x; p < DH * VP; p += kThreads) {
+        const int row = p / VP, c = p % VP;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kc0 + c * 8 < a.Tp) v = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
+        *(uint4*)(lds_v + row * L::VLD + c * 16) = v;
+      }
+    }
+    __syncthreads();
+    if (!active) continue;
+    const int nkt = (min(len - kc0, kKC) + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+      f32x16 s;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        const h8 kf = *(const h8*)(lds_k + (kt * 32 + r) * L::KLD + (ks * 16 + 8 * hh) * 2);
+        s = mfma16(kf, qf[ks], s);
+      }
+      const int key0 = kc0 + kt * 32;
+      float tmax = kNegBig;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (key0 + acc_row(i, lane) >= len) s[i] = kNegBig;
+        tmax = fmaxf(tmax, s[i]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      float psum = 0.f;
+      h8 pf[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float p = __builtin_amdgcn_exp2f(s[i] - m_new);
+        psum += p;
+        pf[i >> 3][i & 7] = (half_t)p;
+      }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const h8 vf = *(const h8*)(lds_v + (dt * 32 + r) * L::VLD + (kt * 32 + ks * 16 + 8 * hh) * 2);
+          o[dt] = mfma16(vf, pf[ks], o[dt]);
+        }
+      }
+    }
+  }
+  if (!active) return;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + r;
+  if (q < a.Tq) {
+    const size_t rowoff = ((size_t)b * a.Tq + q) * kD + hd * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) EEC_SPLIT(o[dt][4 * g + j] * inv, hi, lo, j);
+        const int d = dt * 32 + 8 * g + 4 * hh;
+        *(h4*)(a.o_hi + rowoff + d) = hi;
+        if (NP == 3) *(h4*)(a.o_lo + rowoff + d) = lo;
+      }
+  }
+}
+
+template <int DH, int NP>
+static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
+  auto k = attn_kernel<DH, NP>;
+  constexpr int lds = AttnLds<DH>::TOTAL;
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(kThreads), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st) {
+  if (a.dh == 32) return np == 3 ? launch_attn_t<32, 3>(a, st) : launch_attn_t<32, 1>(a, st);
+  if (a.dh == 64) return np == 3 ? launch_attn_t<64, 3>(a, st) : launch_attn_t<64, 1>(a, st);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace eec

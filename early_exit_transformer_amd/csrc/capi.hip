@@ -1,0 +1,347 @@
+// C-ABI of libeec.so (include/eec.h): parameter packing, workspace carving and the
+// launch plan of one encoder forward.  Host code only; kernels live in the other .hip files.
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/eec.h"
+#include "eec_kernels.h"
+
+using namespace eec;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return (int)e;
+}
+#define EEC_HIP(expr)                                  \
+  do {                                                 \
+    hipError_t _e = (expr);                            \
+    if (_e != hipSuccess) return hip_fail(_e, #expr);  \
+  } while (0)
+
+struct PackedLayer {
+  // device pointers into the encoder's arena
+  float *ffn1_ln_w, *ffn1_ln_b, *ffn1_b1, *ffn1_b2;
+  uint4 *ffn1_w1p, *ffn1_w2p;
+  float *attn_ln_w, *attn_ln_b, *attn_in_b, *attn_out_b;
+  uint4 *attn_in_p, *attn_out_p;
+  float *conv_ln_w, *conv_ln_b, *conv_pw1_b, *conv_pw2_b, *dw_wfold, *dw_bfold;
+  uint4 *conv_pw1_p, *conv_pw2_p;
+  float *ffn2_ln_w, *ffn2_ln_b, *ffn2_b1, *ffn2_b2;
+  uint4 *ffn2_w1p, *ffn2_w2p;
+  float *final_ln_w, *final_ln_b;
+};
+
+size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Arena {  // bump allocator over one hipMalloc
+  char* base = nullptr;
+  size_t cap = 0, off = 0;
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off);
+    T* p = (T*)(base ? base + off : nullptr);
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+size_t frag_u4(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 128; }
+
+}  // namespace
+
+struct eec_encoder {
+  eec_config cfg;
+  Arena arena;
+  bool packed = false;
+  std::vector<PackedLayer> layers;
+  float *sub_w1t, *sub_b1, *sub_w2t, *sub_b2, *pe;
+  std::vector<uint4*> head_p;
+  std::vector<float*> head_b;
+
+  void carve() {
+    const int D = cfg.d_model, F = cfg.d_ff, nl = cfg.n_exits * cfg.layers_per_exit;
+    layers.assign(nl, PackedLayer());
+    for (auto& L : layers) {
+      L.ffn1_ln_w = arena.take<float>(D);
+      L.ffn1_ln_b = arena.take<float>(D);
+      L.ffn1_b1 = arena.take<float>(F);
+      L.ffn1_b2 = arena.take<float>(D);
+      L.ffn1_w1p = arena.take<uint4>(frag_u4(F, D));
+      L.ffn1_w2p = arena.take<uint4>(frag_u4(D, F));
+      L.attn_ln_w = arena.take<float>(D);
+      L.attn_ln_b = arena.take<float>(D);
+      L.attn_in_b = arena.take<float>(3 * D);
+      L.attn_out_b = arena.take<float>(D);
+      L.attn_in_p = arena.take<uint4>(frag_u4(3 * D, D));
+      L.attn_out_p = arena.take<uint4>(frag_u4(D, D));
+      L.conv_ln_w = arena.take<float>(D);
+      L.conv_ln_b = arena.take<float>(D);
+      L.conv_pw1_b = arena.take<float>(2 * D);
+      L.conv_pw2_b = arena.take<float>(D);
+      L.dw_wfold = arena.take<float>(31 * D);
+      L.dw_bfold = arena.take<float>(D);
+      L.conv_pw1_p = arena.take<uint4>(frag_u4(2 * D, D));
+      L.conv_pw2_p = arena.take<uint4>(frag_u4(D, D));
+      L.ffn2_ln_w = arena.take<float>(D);
+      L.ffn2_ln_b = arena.take<float>(D);
+      L.ffn2_b1 = arena.take<float>(F);
+      L.ffn2_b2 = arena.take<float>(D);
+      L.ffn2_w1p = arena.take<uint4>(frag_u4(F, D));
+      L.ffn2_w2p = arena.take<uint4>(frag_u4(D, F));
+      L.final_ln_w = arena.take<float>(D);
+      L.final_ln_b = arena.take<float>(D);
+    }
+    sub_w1t = arena.take<float>((size_t)cfg.n_mels * 3 * D);
+    sub_b1 = arena.take<float>(D);
+    sub_w2t = arena.take<float>((size_t)D * 3 * D);
+    sub_b2 = arena.take<float>(D);
+    pe = arena.take<float>((size_t)cfg.max_len * D);
+    head_p.assign(cfg.n_exits, nullptr);
+    head_b.assign(cfg.n_exits, nullptr);
+    for (int e = 0; e < cfg.n_exits; ++e) {
+      head_p[e] = arena.take<uint4>(frag_u4(cfg.vocab, D));
+      head_b[e] = arena.take<float>(cfg.vocab);
+    }
+    arena.off = align_up(arena.off);
+  }
+};
+
+namespace {
+
+struct Workspace {
+  float *x, *mid;
+  half_t *q, *k, *vt, *p_hi, *p_lo, *g;
+  int* enc_len;
+  size_t bytes;
+};
+
+Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
+  const int T1 = (T - 3) / 2 + 1, Tq = (T1 - 3) / 2 + 1, Tp = (Tq + 31) / 32 * 32;
+  const size_t M = (size_t)B * Tq, D = c.d_model;
+  Arena a;
+  a.base = base;
+  Workspace w;
+  w.x = a.take<float>(M * D);
+  w.mid = a.take<float>((size_t)B * T1 * D);
+  w.q = a.take<half_t>((size_t)B * Tp * D);
+  w.k = a.take<half_t>((size_t)B * Tp * D);
+  w.vt = a.take<half_t>((size_t)B * Tp * D);
+  w.p_hi = a.take<half_t>(M * D);
+  w.p_lo = a.take<half_t>(M * D);
+  w.g = a.take<half_t>(M * D);
+  w.enc_len = a.take<int>(B);
+  w.bytes = align_up(a.off);
+  return w;
+}
+
+int check_cfg(const eec_config& c) {
+  if (c.d_model != kD) return fail(EEC_ERR_UNSUPPORTED, "d_model must be 256 in this build");
+  if (c.n_heads <= 0 || kD % c.n_heads) return fail(EEC_ERR_BAD_ARG, "n_heads must divide d_model");
+  const int dh = kD / c.n_heads;
+  if (dh != 32 && dh != 64) return fail(EEC_ERR_UNSUPPORTED, "head dim must be 32 or 64");
+  if (c.d_ff <= 0 || c.d_ff % 128) return fail(EEC_ERR_UNSUPPORTED, "d_ff must be a positive multiple of 128");
+  if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1))
+    return fail(EEC_ERR_UNSUPPORTED, "depthwise kernel must be odd and <= 31");
+  if (c.vocab <= 0 || c.vocab > 256 || c.vocab % 32) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 32, <= 256");
+  if (c.n_exits <= 0 || c.layers_per_exit <= 0 || c.n_mels <= 0 || c.max_len <= 0)
+    return fail(EEC_ERR_BAD_ARG, "n_exits, layers_per_exit, n_mels, max_len must be positive");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eec_last_error(void) { return g_err.c_str(); }
+int eec_abi_version(void) { return EEC_ABI_VERSION; }
+
+int eec_out_frames(int T) {
+  if (T < 7) return 0;
+  const int T1 = (T - 3) / 2 + 1;
+  return (T1 - 3) / 2 + 1;
+}
+
+int eec_encoder_create(const eec_config* cfg, eec_encoder** out) {
+  if (!cfg || !out) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (int rc = check_cfg(*cfg)) return rc;
+  eec_encoder* enc = new eec_encoder();
+  enc->cfg = *cfg;
+  enc->carve();  // dry run: sizes only
+  const size_t need = enc->arena.off;
+  void* mem = nullptr;
+  hipError_t e = hipMalloc(&mem, need);
+  if (e != hipSuccess) {
+    delete enc;
+    return hip_fail(e, "hipMalloc(packed weights)");
+  }
+  enc->arena = Arena();
+  enc->arena.base = (char*)mem;
+  enc->arena.cap = need;
+  enc->carve();
+  *out = enc;
+  return 0;
+}
+
+void eec_encoder_destroy(eec_encoder* enc) {
+  if (!enc) return;
+  if (enc->arena.base) (void)hipFree(enc->arena.base);
+  delete enc;
+}
+
+int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
+  if (!enc || !p || !p->layers || !p->head_w || !p->head_b) return fail(EEC_ERR_BAD_ARG, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const eec_config& c = enc->cfg;
+  const int D = c.d_model, F = c.d_ff;
+  auto cp = [&](float* dst, const float* src, size_t n) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+  };
+  for (size_t i = 0; i < enc->layers.size(); ++i) {
+    const eec_layer_params& s = p->layers[i];
+    PackedLayer& L = enc->layers[i];
+    EEC_HIP(cp(L.ffn1_ln_w, s.ffn1_ln_w, D));
+    EEC_HIP(cp(L.ffn1_ln_b, s.ffn1_ln_b, D));
+    EEC_HIP(cp(L.ffn1_b1, s.ffn1_b1, F));
+    EEC_HIP(cp(L.ffn1_b2, s.ffn1_b2, D));
+    EEC_HIP(launch_pack_frags(s.ffn1_w1, F, D, L.ffn1_w1p, st));
+    EEC_HIP(launch_pack_frags(s.ffn1_w2, D, F, L.ffn1_w2p, st));
+    EEC_HIP(cp(L.attn_ln_w, s.attn_ln_w, D));
+    EEC_HIP(cp(L.attn_ln_b, s.attn_ln_b, D));
+    EEC_HIP(cp(L.attn_in_b, s.attn_in_b, 3 * D));
+    EEC_HIP(cp(L.attn_out_b, s.attn_out_b, D));
+    EEC_HIP(launch_pack_frags(s.attn_in_w, 3 * D, D, L.attn_in_p, st));
+    EEC_HIP(launch_pack_frags(s.attn_out_w, D, D, L.attn_out_p, st));
+    EEC_HIP(cp(L.conv_ln_w, s.conv_ln_w, D));
+    EEC_HIP(cp(L.conv_ln_b, s.conv_ln_b, D));
+    EEC_HIP(cp(L.conv_pw1_b, s.conv_pw1_b, 2 * D));
+    EEC_HIP(cp(L.conv_pw2_b, s.conv_pw2_b, D));
+    EEC_HIP(launch_pack_frags(s.conv_pw1_w, 2 * D, D, L.conv_pw1_p, st));
+    EEC_HIP(launch_pack_frags(s.conv_pw2_w, D, D, L.conv_pw2_p, st));
+    EEC_HIP(launch_fold_dw(s.conv_dw_w, s.conv_dw_b, s.conv_bn_w, s.conv_bn_b, s.conv_bn_rm, s.conv_bn_rv,
+                           c.dw_kernel, L.dw_wfold, L.dw_bfold, st));
+    EEC_HIP(cp(L.ffn2_ln_w, s.ffn2_ln_w, D));
+    EEC_HIP(cp(L.ffn2_ln_b, s.ffn2_ln_b, D));
+    EEC_HIP(cp(L.ffn2_b1, s.ffn2_b1, F));
+    EEC_HIP(cp(L.ffn2_b2, s.ffn2_b2, D));
+    EEC_HIP(launch_pack_frags(s.ffn2_w1, F, D, L.ffn2_w1p, st));
+    EEC_HIP(launch_pack_frags(s.ffn2_w2, D, F, L.ffn2_w2p, st));
+    EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
+    EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
+  }
+  EEC_HIP(launch_transpose_conv(p->sub0_w, D, c.n_mels, 3, enc->sub_w1t, st));
+  EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+  EEC_HIP(launch_transpose_conv(p->sub1_w, D, D, 3, enc->sub_w2t, st));
+  EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
+  EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
+  for (int e = 0; e < c.n_exits; ++e) {
+    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], st));
+    EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+  }
+  enc->packed = true;
+  return 0;
+}
+
+size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T) {
+  if (!enc || B <= 0 || T < 7) return 0;
+  return carve_ws(enc->cfg, B, T, nullptr).bytes;
+}
+
+int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
+                        float* out, float* taps_opt, void* workspace, size_t workspace_bytes, int stop_after,
+                        float* x_dbg_opt, void* stream) {
+  if (!enc || !mel || !lengths || !workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!out && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "out is null");
+  if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
+  if (B <= 0 || T < 7) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 7 (two k=3 s=2 convs)");
+  if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16) return fail(EEC_ERR_BAD_ARG, "unknown precision");
+  const eec_config& c = enc->cfg;
+  const int T1 = (T - 3) / 2 + 1, Tq = (T1 - 3) / 2 + 1, Tp = (Tq + 31) / 32 * 32;
+  if (Tq > c.max_len) return fail(EEC_ERR_BAD_ARG, "T' exceeds the positional-encoding table (max_len)");
+  if (((uintptr_t)workspace & 255) != 0) return fail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  Workspace ws = carve_ws(c, B, T, (char*)workspace);
+  if (workspace_bytes < ws.bytes) return fail(EEC_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : 1;
+  const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
+  const int M = B * Tq, D = c.d_model, H = c.n_heads;
+  int step = 0;
+  auto done = [&](void) -> bool { return stop_after >= 0 && step > stop_after; };
+  auto finish_dbg = [&]() -> int {
+    if (x_dbg_opt) EEC_HIP(hipMemcpyAsync(x_dbg_opt, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+  };
+
+  EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
+  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
+  {
+    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1t, enc->sub_b1, enc->sub_w2t, enc->sub_b2, enc->pe, ws.mid, ws.x};
+    EEC_HIP(launch_subsample(a, st));
+  }
+  ++step;
+  if (done()) return finish_dbg();
+
+  for (int e = 0; e < c.n_exits; ++e) {
+    for (int l = 0; l < c.layers_per_exit; ++l) {
+      const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
+      {
+        FfnArgs a{ws.x, M, c.d_ff, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr};
+        EEC_HIP(launch_ffn(a, np_ffn, st));
+      }
+      ++step;
+      if (done()) return finish_dbg();
+      {
+        QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+        EEC_HIP(launch_qkv(a, np_o, st));
+        AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+        EEC_HIP(launch_attention(at, np_o, st));
+        ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+        EEC_HIP(launch_proj_residual(pr, np_o, st));
+      }
+      ++step;
+      if (done()) return finish_dbg();
+      {
+        GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
+        EEC_HIP(launch_pw1_glu(ga, np_o, st));
+        DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
+        EEC_HIP(launch_dwconv(da, np_o, st));
+        ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.conv_pw2_p, L.conv_pw2_b};
+        EEC_HIP(launch_proj_residual(pr, np_o, st));
+      }
+      ++step;
+      if (done()) return finish_dbg();
+      {
+        FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b};
+        EEC_HIP(launch_ffn(a, np_ffn, st));
+      }
+      ++step;
+      if (done()) return finish_dbg();
+    }
+    if (out) {
+      HeadArgs h{ws.x, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+      EEC_HIP(launch_head(h, np_o, st));
+    }
+    if (taps_opt)
+      EEC_HIP(hipMemcpyAsync(taps_opt + (size_t)e * M * D, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+  }
+  return finish_dbg();
+}
+
+int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32_t* tokens, int32_t* counts,
+                   void* stream) {
+  if (!logp || !tokens || !counts || n_seq <= 0 || Tq <= 0 || V <= 0) return fail(EEC_ERR_BAD_ARG, "bad argument");
+  EEC_HIP(launch_greedy_ctc(logp, n_seq, Tq, V, blank, tokens, counts, (hipStream_t)stream));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,262 @@
+// Shared device-side building blocks for the gfx950 (CDNA4, wave64) encoder kernels.
+//
+// Conventions used by every kernel in this directory
+// ---------------------------------------------------
+// * A "row tile" is 64 consecutive rows of the flattened (utterance x frame)
+//   axis M = B*T'.  One 256-thread workgroup (4 waves, one per SIMD) owns one
+//   row tile and all of the output columns of it; M/64 = 256 tiles at the
+//   headline shape = one workgroup per CU.
+// * 16-bit operands are fp16.  "NP" = number of MFMA passes per product:
+//     NP=1  a_hi*w_hi                                   (plain fp16 operands)
+//     NP=3  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi           (hi/lo split, ~2^-21)
+//   with x = hi + lo, hi = fp16(x), lo = fp16(x - hi).  The reference computes
+//   in fp32; single-pass 16-bit operands miss its 1e-3 log-prob
+//   tolerance by 2.7x (fp16) / 25x (bf16), the split meets it with margin.
+// * MFMA shape: v_mfma_f32_32x32x16_f16.  Lane l: r = l & 31, h = l >> 5.
+//     A operand: lane holds A[row r][k = 8h + j], j = 0..7
+//     B operand: lane holds B[k = 8h + j][col r]
+//     C/D      : col = r, row = (reg & 3) + 8 * (reg >> 2) + 4 * h, reg = 0..15
+//   Both operand fragments of an activation tile Act[m][k] and of a weight
+//   matrix W[n][k] (torch Linear layout, k contiguous) are therefore "row r,
+//   8 consecutive k starting at 16*s + 8*h": the same 16-byte read.  Passing
+//   (act, w) gives acc[m][n] ("normal"); passing (w, act) gives acc[n][m]
+//   ("swapped": frames on lanes, output features in registers).
+// * Packed weights: fragment (nt, s) of W[N][K] is the 32 rows [32nt, 32nt+32)
+//   x 16 k [16s, 16s+16) stored lane-linear: uint4 index
+//       ((nt * KS + s) * 2 + plane) * 64 + lane,   KS = K / 16, plane 0 = hi, 1 = lo
+//   so a wave reads one fragment as one contiguous 1 KiB global_load_dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace eec {
+
+typedef _Float16 half_t;
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+constexpr int kTileRows = 64;      // rows of M per workgroup
+constexpr int kThreads = 256;      // 4 waves
+constexpr int kD = 256;            // d_model this build is specialised for
+constexpr float kLnEps = 1e-5f;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kHalfMax = 65504.0f;
+
+// LDS geometry (bytes).  Row pads of one 16-B slot make ds_read_b128 of
+// "32 different rows, same column" conflict-free (stride = 4 banks mod 64).
+constexpr int kALd = (kD + 8) * 2;            // 528  : [64][256] fp16 activation plane
+constexpr int kAPlane = kTileRows * kALd;     // 33792
+constexpr int kELd = (kD + 4) * 4;            // 1040 : [64][256] fp32 epilogue tile
+constexpr int kETile = kTileRows * kELd;      // 66560 (aliases the two A planes: 67584)
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ half_t to_half_sat(float x) {
+  return (half_t)fminf(fmaxf(x, -kHalfMax), kHalfMax);
+}
+// hi/lo split of one fp32 value.
+struct hl_t {
+  half_t hi, lo;
+};
+__device__ __forceinline__ hl_t split_hl(float x) {
+  hl_t r;
+  r.hi = to_half_sat(x);
+  r.lo = (half_t)(x - (float)r.hi);
+  return r;
+}
+// vector elements cannot bind to references: assign through a temporary
+#define EEC_SPLIT(val, HI, LO, idx)       \
+  do {                                    \
+    const hl_t _t = split_hl(val);        \
+    (HI)[idx] = _t.hi;                    \
+    (LO)[idx] = _t.lo;                    \
+  } while (0)
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// row of accumulator register i for this lane (within a 32x32 tile)
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------
+// One GEMM stage: acc[MT][NT] += Act(LDS planes) x W(packed, global).
+//   lds_act   : byte address of plane 0, row 0 of the activation tile
+//   ld_bytes  : row stride, plane_bytes: distance hi -> lo plane
+//   wfrag     : packed weights; fragment (nt, s) at wfrag[((nt*ks_total + s)*2 + p)*64 + lane]
+//   nt0       : first n-tile of this wave, s0: first k-step of W, KS steps are consumed;
+//               activation k starts at column 0 of the LDS tile.
+//   SWAP      : false -> acc[mt][nt] is [m rows][n lanes]; true -> [n rows][m lanes]
+// Weight fragments are prefetched PF k-steps ahead in registers.
+// ---------------------------------------------------------------------------
+template <int NP, int KS, int MT, int NT, bool SWAP, int PF = 2>
+__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[MT][NT], const char* lds_act, int ld_bytes,
+                                           int plane_bytes, const uint4* __restrict__ wfrag,
+                                           int ks_total, int nt0, int s0) {
+  const int lane = lane_id();
+  constexpr int NPL = (NP == 3) ? 2 : 1;
+  const char* a_ptr = lds_act + (lane & 31) * ld_bytes + (lane >> 5) * 16;
+  const uint4* w_ptr = wfrag + ((size_t)(nt0 * ks_total + s0) * 2) * 64 + lane;
+  const size_t nt_stride = (size_t)ks_total * 2 * 64;
+
+  uint4 wq[PF][NT][NPL];
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < KS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) wq[p][nt][pl] = w_ptr[nt * nt_stride + (size_t)(p * 2 + pl) * 64];
+    }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    h8 ah[MT], al[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      ah[mt] = *(const h8*)(a_ptr + mt * 32 * ld_bytes + s * 32);
+      if (NP == 3) al[mt] = *(const h8*)(a_ptr + plane_bytes + mt * 32 * ld_bytes + s * 32);
+    }
+    h8 bh[NT], bl[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bh[nt] = __builtin_bit_cast(h8, wq[s % PF][nt][0]);
+      if (NP == 3) bl[nt] = __builtin_bit_cast(h8, wq[s % PF][nt][NPL - 1]);
+    }
+    if (s + PF < KS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl)
+          wq[s % PF][nt][pl] = w_ptr[nt * nt_stride + (size_t)((s + PF) * 2 + pl) * 64];
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        if (!SWAP) {
+          if (NP == 3) {
+            acc[mt][nt] = mfma16(al[mt], bh[nt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(ah[mt], bl[nt], acc[mt][nt]);
+          }
+          acc[mt][nt] = mfma16(ah[mt], bh[nt], acc[mt][nt]);
+        } else {
+          if (NP == 3) {
+            acc[mt][nt] = mfma16(bh[nt], al[mt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(bl[nt], ah[mt], acc[mt][nt]);
+          }
+          acc[mt][nt] = mfma16(bh[nt], ah[mt], acc[mt][nt]);
+        }
+      }
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Prologues: fill the [64][256] activation planes in LDS.
+// Each wave handles 16 rows; a row is one coalesced 1 KiB float4 load.
+// ---------------------------------------------------------------------------
+// x fp32 [M][256] -> (optional LayerNorm) -> hi/lo planes.
+template <int NP, bool DO_LN>
+__device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* __restrict__ x, int row0, int M,
+                                                   const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta) {
+  const int lane = lane_id(), w = wave_id();
+  float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (DO_LN) {
+    g = ((const float4*)gamma)[lane];
+    bt = ((const float4*)beta)[lane];
+  }
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int rl = w * 16 + i, row = row0 + rl;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < M) v = ((const float4*)(x + (size_t)row * kD))[lane];
+    if (DO_LN) {
+      const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / kD);
+      const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+      const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / kD);
+      const float rs = rsqrtf(var + kLnEps);
+      v.x = dx * rs * g.x + bt.x;
+      v.y = dy * rs * g.y + bt.y;
+      v.z = dz * rs * g.z + bt.z;
+      v.w = dw * rs * g.w + bt.w;
+      if (row >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    h4 hi, lo;
+    EEC_SPLIT(v.x, hi, lo, 0);
+    EEC_SPLIT(v.y, hi, lo, 1);
+    EEC_SPLIT(v.z, hi, lo, 2);
+    EEC_SPLIT(v.w, hi, lo, 3);
+    *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
+    if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
+  }
+}
+
+// fp16 planes in global ([M][256] hi, [M][256] lo) -> LDS planes.
+template <int NP>
+__device__ __forceinline__ void rows_planes_to_lds(char* lds_act, const half_t* __restrict__ hi,
+                                                   const half_t* __restrict__ lo, int row0, int M) {
+  const int t = threadIdx.x;
+  // 64 rows x 512 B per plane = 2048 16-byte pieces; 256 threads x 8
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int piece = it * kThreads + t;
+    const int rl = piece >> 5, c16 = piece & 31;
+    const int row = row0 + rl;
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+    if (row < M) {
+      vh = *(const uint4*)(hi + (size_t)row * kD + c16 * 8);
+      if (NP == 3) vl = *(const uint4*)(lo + (size_t)row * kD + c16 * 8);
+    }
+    *(uint4*)(lds_act + rl * kALd + c16 * 16) = vh;
+    if (NP == 3) *(uint4*)(lds_act + kAPlane + rl * kALd + c16 * 16) = vl;
+  }
+}
+
+// acc[MT=2][NT] (normal orientation, wave owns columns col0 + nt*32 ..) + bias -> fp32 tile in LDS.
+template <int NT>
+__device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2][NT], int col0,
+                                             const float* __restrict__ bias) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = col0 + nt * 32 + (lane & 31);
+    const float b = bias ? bias[col] : 0.0f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int r = mt * 32 + acc_row(i, lane);
+        *(float*)(lds_e + r * kELd + col * 4) = acc[mt][nt][i] + b;
+      }
+  }
+}
+
+}  // namespace eec

@@ -1,0 +1,97 @@
+// Internal (non-ABI) declarations: kernel argument blocks and host launchers.
+#pragma once
+#include "eec_device.h"
+
+namespace eec {
+
+struct FfnArgs {
+  float* x;  // [M][256] fp32, updated in place
+  int M, F;
+  const float *ln_g, *ln_b;
+  const uint4* w1p;  // packed [F][256]
+  const float* b1;
+  const uint4* w2p;  // packed [256][F]
+  const float* b2;
+  const float *fin_g, *fin_b;  // optional final LayerNorm (nullptr = none)
+};
+hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st);
+
+struct QkvArgs {
+  const float* x;  // [M][256]
+  int M, B, Tq, Tp, H;  // Tq = T' (frames per utterance), Tp = padded to 32
+  const float *ln_g, *ln_b;
+  const uint4* wp;  // packed in_proj_weight [768][256]
+  const float* bias;  // [768]
+  half_t *q, *k, *vt;  // q,k: [B][H][Tp][dh]; vt: [B][H][dh][Tp] (key order permuted per 16)
+};
+hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
+
+struct ProjResArgs {  // x += planes . W^T + bias   (attention out-proj, conv pointwise-2)
+  float* x;
+  int M;
+  const half_t *a_hi, *a_lo;  // [M][256]
+  const uint4* wp;            // packed [256][256]
+  const float* bias;
+};
+hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st);
+
+struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,256), gate cols [256,512)
+  const float* x;
+  int M;
+  const float *ln_g, *ln_b;
+  const uint4* wp;  // packed [512][256]
+  const float* bias;
+  half_t* g;  // [M][256] fp16
+};
+hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st);
+
+struct HeadArgs {  // out = log_softmax(x . W^T + b)
+  const float* x;
+  int M, V;
+  const uint4* wp;  // packed [V][256]
+  const float* bias;
+  float* out;  // [M][V]
+};
+hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st);
+
+struct AttnArgs {
+  const half_t *q, *k, *vt;
+  const int* enc_len;  // [B] valid encoder frames (keys >= len are masked)
+  int B, H, Tq, Tp, dh;
+  half_t *o_hi, *o_lo;  // [M][256]
+};
+hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st);
+
+struct DwArgs {
+  const half_t* g;  // [B*Tq][256]
+  int B, Tq;
+  const float* wfold;  // [31][256] taps (BN folded, zero padded to 31, centred)
+  const float* bfold;  // [256]
+  half_t *o_hi, *o_lo;
+};
+hipError_t launch_dwconv(const DwArgs& a, int np, hipStream_t st);
+
+struct SubsampleArgs {
+  const float* mel;  // [B][n_mels][T]
+  int B, n_mels, T, T1, Tq;
+  const float *w1t, *b1;  // w1t: [n_mels*3][256]
+  const float *w2t, *b2;  // w2t: [256*3][256]
+  const float* pe;        // [max_len][256]
+  float* mid;             // [B][T1][256] scratch
+  float* x;               // [B*Tq][256]
+};
+hipError_t launch_subsample(const SubsampleArgs& a, hipStream_t st);
+
+// weight packing (device -> device)
+hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, hipStream_t st);  // W[N][K] -> fragments
+hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
+                          const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,
+                          hipStream_t st);
+hipError_t launch_transpose_conv(const float* w, int cout, int cin, int ks, float* out, hipStream_t st);  // [co][ci][j] -> [ci*ks+j][co]
+hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_len, hipStream_t st);
+
+// greedy CTC (argmax -> unique_consecutive -> drop blank)
+hipError_t launch_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int* tokens, int* counts,
+                             hipStream_t st);
+
+}  // namespace eec

@@ -1,0 +1,86 @@
+// Weight packing, length conversion and greedy CTC decode.
+#include "eec_kernels.h"
+
+namespace eec {
+
+// W[N][K] fp32 (torch Linear / 1x1-conv layout) -> MFMA fragments, hi and lo fp16 planes.
+// out[((nt*KS + s)*2 + plane)*64 + lane] = 8 halves W[32nt + (lane&31)][16s + 8(lane>>5) + j]
+__global__ void pack_frags_kernel(const float* __restrict__ w, int N, int K, uint4* __restrict__ out, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, frag = idx >> 6;
+  const int KS = K / 16;
+  const int nt = frag / KS, s = frag - nt * KS;
+  const int n = nt * 32 + (lane & 31), k0 = s * 16 + 8 * (lane >> 5);
+  h8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (n < N) ? w[(size_t)n * K + k0 + j] : 0.f;
+    EEC_SPLIT(v, hi, lo, j);
+  }
+  out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
+  out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, hipStream_t st) {
+  if (K % 16) return hipErrorInvalidValue;
+  const int total = ((N + 31) / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, K, out, total);
+  return hipGetLastError();
+}
+
+// enc_len[b] = int(clamp(float(len) / 4, max = T'))   (reference early_exit.py:623: true division, truncation)
+__global__ void enc_lengths_kernel(const long long* lengths, int B, int Tq, int* enc_len) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) enc_len[b] = (int)fminf((float)lengths[b] / 4.0f, (float)Tq);
+}
+
+hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_len, hipStream_t st) {
+  hipLaunchKernelGGL(enc_lengths_kernel, dim3((B + 63) / 64), dim3(64), 0, st, lengths, B, Tq, enc_len);
+  return hipGetLastError();
+}
+
+// Greedy CTC (reference util/beam_infer.py:9-24): argmax over labels, collapse repeats, drop blank.
+// One wave per sequence; frames are walked 64 at a time, kept tokens compacted with a ballot.
+// Ties in the argmax resolve to the lowest label index (torch.argmax on CPU).
+__global__ __launch_bounds__(64) void greedy_ctc_kernel(const float* __restrict__ logp, int Tq, int V, int blank,
+                                                        int* __restrict__ tokens, int* __restrict__ counts) {
+  const int seq = blockIdx.x, lane = threadIdx.x;
+  const float* base = logp + (size_t)seq * Tq * V;
+  int* out = tokens + (size_t)seq * Tq;
+  int n_out = 0, prev_last = -1;
+  for (int t0 = 0; t0 < Tq; t0 += 64) {
+    const int t = t0 + lane;
+    int best = -1;
+    if (t < Tq) {
+      const float* row = base + (size_t)t * V;
+      float bv = row[0];
+      best = 0;
+      for (int v = 1; v < V; ++v) {
+        const float x = row[v];
+        if (x > bv) {
+          bv = x;
+          best = v;
+        }
+      }
+    }
+    int prev = __shfl_up(best, 1, 64);
+    if (lane == 0) prev = prev_last;
+    const bool keep = (t < Tq) && (best != prev) && (best != blank);
+    const unsigned long long mask = __ballot(keep);
+    const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+    if (keep) out[n_out + pos] = best;
+    n_out += __popcll(mask);
+    const int last_lane = min(63, Tq - 1 - t0);
+    prev_last = __shfl(best, last_lane, 64);
+  }
+  if (lane == 0) counts[seq] = n_out;
+}
+
+hipError_t launch_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int* tokens, int* counts,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(greedy_ctc_kernel, dim3(n_seq), dim3(64), 0, st, logp, Tq, V, blank, tokens, counts);
+  return hipGetLastError();
+}
+
+}  // namespace eec

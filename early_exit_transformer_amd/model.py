@@ -1,0 +1,264 @@
+"""Drop-in mirrors of the reference's ``Early_conformer`` / ``full_conformer``.
+
+Same constructor keywords, ``forward`` signatures, return shapes and state_dict keys as
+/root/reference/models/model/early_exit.py:565-634 (Early_conformer) and :637-811
+(full_conformer), as called from train.py:148-178,37,54 and inference.py:45-46,66.
+The encoder stack (subsampling, positional encoding, length mask, E x L Conformer layers,
+per-exit Linear + log_softmax) is ONE call into libeec.so on the caller's current HIP
+stream; there is no PyTorch implementation of it in this package and no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import capi
+from .conformer import Conformer
+
+
+class PositionalEncoding(nn.Module):
+    """Holder of the sinusoid table buffer ``pe`` [max_len, 1, d_model] (reference
+    models/embedding/positional_encoding.py:55-64).  The add happens inside the stem kernel."""
+
+    def __init__(self, d_model: int, dropout: float, max_len: int):
+        super().__init__()
+        self.dropout = nn.Dropout(dropout)
+        t = torch.arange(max_len).unsqueeze(1)
+        w = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, 1, d_model)
+        pe[:, 0, 0::2] = torch.sin(t * w)
+        pe[:, 0, 1::2] = torch.cos(t * w)
+        self.register_buffer("pe", pe)
+
+    def forward(self, x: Tensor) -> Tensor:  # used by the AED decoder side only: [B, S, D]
+        return self.dropout(x + self.pe[: x.size(1), 0].unsqueeze(0))
+
+
+class Conv1dSubampling(nn.Module):
+    """Parameter holder for the two Conv1d(k=3, s=2) of the stem (early_exit.py:24-48)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.sequential = nn.Sequential(
+            nn.Conv1d(in_channels, out_channels, kernel_size=3, stride=2, padding=0),
+            nn.Conv1d(out_channels, out_channels, kernel_size=3, stride=2, padding=0))
+
+
+class _HipEncoderMixin:
+    """Owns the libeec encoder handle, the packed-weight cache and the workspace."""
+
+    _head_attr = "linears"
+    _pe_attr = "positional_encoder"
+    precision = "f16x3"
+
+    def _hip_init(self, d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len):
+        self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len)
+        self._enc = None
+        self._packed_key = None
+        self._ws: Dict[Tuple[int, int, int], Tensor] = {}
+        self._keep: list = []
+
+    def __del__(self):
+        enc = getattr(self, "_enc", None)
+        if enc is not None:
+            try:
+                capi.load().eec_encoder_destroy(enc)
+            except Exception:
+                pass
+
+    # -- packing ------------------------------------------------------------
+    def _param_tensors(self) -> List[Tensor]:
+        return list(self.conv_subsample.parameters()) + list(self.conformer.parameters()) + \
+            list(self.conformer.buffers()) + list(getattr(self, self._head_attr).parameters()) + \
+            [getattr(self, self._pe_attr).pe]
+
+    def _ensure_packed(self, device: torch.device) -> None:
+        tensors = self._param_tensors()
+        key = (device, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        if self._enc is not None and key == self._packed_key:
+            return
+        lib = capi.load()
+        if self._enc is None:
+            h = C.c_void_p()
+            capi.check(lib.eec_encoder_create(C.byref(self._cfg), C.byref(h)), "eec_encoder_create")
+            self._enc = h
+        sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
+
+        def ptr(name: str) -> int:
+            t = sd[name]
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {device}")
+            return t.data_ptr()
+
+        E, L = self._cfg.n_exits, self._cfg.layers_per_exit
+        layers = (capi.EecLayerParams * (E * L))()
+        for e in range(E):
+            for l in range(L):
+                lp = layers[e * L + l]
+                for field, suffix in capi.LAYER_KEYS.items():
+                    setattr(lp, field, ptr(f"conformer.{e}.conformer_layers.{l}.{suffix}"))
+        hw = (C.c_void_p * E)(*[ptr(f"{self._head_attr}.{e}.weight") for e in range(E)])
+        hb = (C.c_void_p * E)(*[ptr(f"{self._head_attr}.{e}.bias") for e in range(E)])
+        params = capi.EecParams(ptr("conv_subsample.sequential.0.weight"), ptr("conv_subsample.sequential.0.bias"),
+                                ptr("conv_subsample.sequential.1.weight"), ptr("conv_subsample.sequential.1.bias"),
+                                ptr(f"{self._pe_attr}.pe"), layers, hw, hb)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        capi.check(lib.eec_encoder_pack(self._enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
+        self._packed_key = key
+
+    # -- forward ------------------------------------------------------------
+    def _workspace(self, B: int, T: int, device: torch.device) -> Tensor:
+        k = (B, T, device.index or 0)
+        ws = self._ws.get(k)
+        if ws is None:
+            n = capi.load().eec_encoder_workspace_bytes(self._enc, B, T)
+            if len(self._ws) > 4:
+                self._ws.clear()
+            ws = torch.empty(n + 256, dtype=torch.uint8, device=device)
+            self._ws[k] = ws
+        return ws
+
+    def _run_encoder(self, src: Tensor, lengths: Tensor, want_out: bool = True, want_taps: bool = False,
+                     stop_after: int = -1, want_x: bool = False):
+        if not src.is_cuda:
+            raise RuntimeError("the MI355X encoder runs on a HIP device only; move the model and inputs to "
+                               "'cuda' (there is no CPU fallback -- the CPU reference lives in oracle/).")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training (autograd through the HIP encoder, batch-stat BatchNorm, dropout) "
+                                      "is not built yet; call under model.eval() / torch.no_grad()")
+        if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
+            raise ValueError(f"src must be [B, {self._cfg.n_mels}, T], got {tuple(src.shape)}")
+        dev = src.device
+        with torch.cuda.device(dev):
+            self._ensure_packed(dev)
+            lib = capi.load()
+            B, _, T = src.shape
+            Tq = lib.eec_out_frames(T)
+            if Tq <= 0:
+                raise ValueError("T too short for two k=3 s=2 convolutions")
+            src = src.contiguous().float()
+            len_dev = lengths.to(device=dev, dtype=torch.int64).contiguous()
+            E, D, V = self._cfg.n_exits, self._cfg.d_model, self._cfg.vocab
+            out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev) if want_out else None
+            taps = torch.empty((E, B, Tq, D), dtype=torch.float32, device=dev) if want_taps else None
+            xdbg = torch.empty((B, Tq, D), dtype=torch.float32, device=dev) if want_x else None
+            ws = self._workspace(B, T, dev)
+            ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.eec_encoder_forward(
+                self._enc, src.data_ptr(), len_dev.data_ptr(), B, T, capi.PRECISIONS[self.precision],
+                out.data_ptr() if out is not None else None, taps.data_ptr() if taps is not None else None,
+                ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), stop_after,
+                xdbg.data_ptr() if xdbg is not None else None, C.c_void_p(stream))
+            capi.check(rc, "eec_encoder_forward")
+            # src/len_dev must outlive the asynchronous launches on this stream
+            src.record_stream(torch.cuda.current_stream(dev))
+            len_dev.record_stream(torch.cuda.current_stream(dev))
+        return out, taps, xdbg
+
+
+class Early_conformer(_HipEncoderMixin, nn.Module):
+    """CTC early-exit Conformer; ``forward(src[B,n_mels,T], lengths[B]) -> [E,B,T',V]`` log-probs."""
+
+    def __init__(self, src_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head, max_len,
+                 d_feed_forward, n_enc_layers, features_length, drop_prob, depthwise_kernel_size, device=None):
+        nn.Module.__init__(self)
+        self.input_dim, self.num_heads, self.ffn_dim = d_model, n_head, d_feed_forward
+        self.num_layers, self.depthwise_conv_kernel_size = n_enc_layers, depthwise_kernel_size
+        self.n_enc_exits, self.dropout, self.device, self.src_pad_idx = n_enc_exits, drop_prob, device, src_pad_idx
+        self.conv_subsample = Conv1dSubampling(features_length, d_model)
+        self.positional_encoder = PositionalEncoding(d_model, drop_prob, max_len)
+        self.linears = nn.ModuleList([nn.Linear(d_model, dec_voc_size) for _ in range(n_enc_exits)])
+        self.conformer = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_feed_forward, num_layers=n_enc_layers,
+                      depthwise_conv_kernel_size=depthwise_kernel_size, dropout=drop_prob)
+            for _ in range(n_enc_exits)])
+        self._hip_init(d_model, n_head, d_feed_forward, depthwise_kernel_size, n_enc_exits, n_enc_layers,
+                       features_length, dec_voc_size, max_len)
+
+    def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        return self._run_encoder(src, lengths)[0]
+
+    def greedy_decode(self, enc_out: Tensor, blank: int = 0) -> List[List[List[int]]]:
+        """Batched GreedyCTCDecoder (util/beam_infer.py:9-24) over every exit and utterance."""
+        E, B, Tq, V = enc_out.shape
+        tokens, counts = greedy_ctc(enc_out.reshape(E * B, Tq, V), blank)
+        tokens, counts = tokens.cpu(), counts.cpu()
+        return [[tokens[e * B + b, : counts[e * B + b]].tolist() for b in range(B)] for e in range(E)]
+
+
+def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
+    """[N, T', V] fp32 log-probs on the GPU -> (tokens [N, T'] int32, counts [N] int32)."""
+    if not logp.is_cuda:
+        raise RuntimeError("greedy_ctc runs on a HIP device only")
+    logp = logp.contiguous().float()
+    N, Tq, V = logp.shape
+    tokens = torch.empty((N, Tq), dtype=torch.int32, device=logp.device)
+    counts = torch.empty((N,), dtype=torch.int32, device=logp.device)
+    with torch.cuda.device(logp.device):
+        stream = torch.cuda.current_stream(logp.device).cuda_stream
+        capi.check(capi.load().eec_greedy_ctc(logp.data_ptr(), N, Tq, V, blank, tokens.data_ptr(),
+                                              counts.data_ptr(), C.c_void_p(stream)), "eec_greedy_ctc")
+    return tokens, counts
+
+
+class full_conformer(_HipEncoderMixin, nn.Module):
+    """AED model: HIP encoder (this repo's scope) + the reference's PyTorch attention decoder
+    (``nn.TransformerDecoder`` stays on PyTorch-ROCm)."""
+
+    _head_attr = "linears_1"
+    _pe_attr = "positional_encoder_1"
+
+    def __init__(self, trg_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head, max_len,
+                 d_feed_forward, n_enc_layers, n_dec_layers, features_length, drop_prob, depthwise_kernel_size,
+                 device=None):
+        nn.Module.__init__(self)
+        self.input_dim, self.num_heads, self.ffn_dim = d_model, n_head, d_feed_forward
+        self.num_layers, self.depthwise_conv_kernel_size = n_enc_layers, depthwise_kernel_size
+        self.n_enc_exits, self.dropout, self.n_dec_layers = n_enc_exits, drop_prob, n_dec_layers
+        self.device, self.trg_pad_idx = device, trg_pad_idx
+        self.layer_norm = nn.LayerNorm(d_model, eps=1e-5)
+        self.emb = nn.Embedding(dec_voc_size, d_model)
+        self.conv_subsample = Conv1dSubampling(features_length, d_model)
+        self.linears_1 = nn.ModuleList([nn.Linear(d_model, dec_voc_size) for _ in range(n_enc_exits)])
+        self.linears_2 = nn.ModuleList([nn.Linear(d_model, dec_voc_size) for _ in range(n_enc_exits)])
+        self.positional_encoder_1 = PositionalEncoding(d_model, drop_prob, max_len)
+        self.positional_encoder_2 = PositionalEncoding(d_model, drop_prob, max_len)
+        self.conformer = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_feed_forward, num_layers=n_enc_layers,
+                      depthwise_conv_kernel_size=depthwise_kernel_size, dropout=drop_prob)
+            for _ in range(n_enc_exits)])
+        self.decoders = nn.ModuleList([
+            nn.TransformerDecoder(
+                nn.TransformerDecoderLayer(d_model=d_model, nhead=n_head, dim_feedforward=d_feed_forward,
+                                           dropout=drop_prob, batch_first=True, norm_first=True),
+                n_dec_layers, self.layer_norm)
+            for _ in range(n_enc_exits)])
+        self._hip_init(d_model, n_head, d_feed_forward, depthwise_kernel_size, n_enc_exits, n_enc_layers,
+                       features_length, dec_voc_size, max_len)
+
+    def _encoder_(self, src: Tensor, lengths: Tensor, layer_n: int) -> Tensor:
+        """Pre-head activations after ``layer_n`` exit groups, [B, T', D] (early_exit.py:719-737)."""
+        L = self._cfg.layers_per_exit
+        n = int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits  # reference loop
+        return self._run_encoder(src, lengths, want_out=False, stop_after=4 * L * n, want_x=True)[2]
+
+    def _decode_one(self, trg: Tensor, enc: Tensor, idx: int) -> Tensor:
+        sz = trg.size(1)
+        tgt_mask = torch.triu(torch.full((sz, sz), float("-inf"), device=trg.device), diagonal=1)
+        pad_mask = trg == self.trg_pad_idx
+        t = self.positional_encoder_2(self.emb(trg))
+        return self.linears_2[idx](self.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=pad_mask))
+
+    def _decoder_(self, trg: Tensor, enc: Tensor, layer_n: int) -> Tensor:
+        idx = (int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits) - 1
+        return torch.log_softmax(self._decode_one(trg, enc, idx), dim=2)
+
+    def forward(self, src: Tensor, lengths: Tensor, trg: Tensor):
+        enc_out, taps, _ = self._run_encoder(src, lengths, want_taps=True)
+        dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
+        return dec_out, enc_out

@@ -1,0 +1,117 @@
+/* eec.h -- C ABI of the MI355X-native early-exit Conformer encoder (libeec.so).
+ *
+ * The reference (augustgw/early-exit-transformer) has no FFI / plugin registry: its
+ * drop-in boundary is the Python class `Early_conformer` / `full_conformer`
+ * (models/model/early_exit.py:565-634, 637-800) as called from train.py:54,37 and
+ * inference.py:66,45.  This library sits behind this repo's own nn.Module mirror of
+ * that class (early_exit_transformer_amd/model.py); every entry point below states the
+ * reference code it replaces.  Plain pointers and sizes only: all `const float*`,
+ * `void* workspace` etc. are DEVICE pointers (HIP), `stream` is a hipStream_t passed as
+ * void*.  Every function returns 0 on success, a non-zero hipError_t / EEC_ERR_* code
+ * otherwise; eec_last_error() returns a thread-local message.  No entry point allocates,
+ * frees or synchronises the device except create/destroy/pack.
+ */
+#ifndef EEC_H_
+#define EEC_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EEC_ABI_VERSION 1
+#define EEC_ERR_BAD_ARG 10001
+#define EEC_ERR_UNSUPPORTED 10002
+#define EEC_ERR_WORKSPACE 10003
+#define EEC_ERR_NOT_PACKED 10004
+
+/* Operand precision of the MFMA products (accumulation, residual stream, LayerNorm,
+ * softmax and log-softmax are always fp32).  The reference computes everything in fp32. */
+enum {
+  EEC_PREC_F16X3 = 0, /* hi/lo-split fp16, 3 MFMA passes per GEMM: |dlogp| ~2e-4, parity mode   */
+  EEC_PREC_MIXED = 1, /* feed-forward GEMMs single-pass fp16, all others split: |dlogp| ~1e-3  */
+  EEC_PREC_F16 = 2    /* every GEMM single-pass fp16: |dlogp| ~3e-3                            */
+};
+
+/* Constructor kwargs of Early_conformer that shape the encoder (early_exit.py:567-615;
+ * flags util/conf.py --d_model --n_heads --d_feed_forward --depthwise_kernel_size
+ * --n_enc_exits --n_enc_layers_per_exit --n_mels, dec_voc_size, --max_len). */
+typedef struct eec_config {
+  int32_t d_model;         /* 256 in this build */
+  int32_t n_heads;         /* d_model / n_heads in {32, 64} */
+  int32_t d_ff;            /* multiple of 128 */
+  int32_t dw_kernel;       /* odd, <= 31 */
+  int32_t n_exits;         /* E */
+  int32_t layers_per_exit; /* L */
+  int32_t n_mels;          /* features_length */
+  int32_t vocab;           /* dec_voc_size: multiple of 32, <= 256 */
+  int32_t max_len;         /* rows of the positional-encoding table */
+} eec_config;
+
+/* fp32 parameters of one torchaudio ConformerLayer, by state_dict key suffix. */
+typedef struct eec_layer_params {
+  const float *ffn1_ln_w, *ffn1_ln_b;   /* ffn1.sequential.0.{weight,bias}          [D]      */
+  const float *ffn1_w1, *ffn1_b1;       /* ffn1.sequential.1.{weight,bias}          [F,D],[F]*/
+  const float *ffn1_w2, *ffn1_b2;       /* ffn1.sequential.4.{weight,bias}          [D,F],[D]*/
+  const float *attn_ln_w, *attn_ln_b;   /* self_attn_layer_norm.{weight,bias}                */
+  const float *attn_in_w, *attn_in_b;   /* self_attn.in_proj_{weight,bias}          [3D,D]   */
+  const float *attn_out_w, *attn_out_b; /* self_attn.out_proj.{weight,bias}         [D,D]    */
+  const float *conv_ln_w, *conv_ln_b;   /* conv_module.layer_norm.{weight,bias}              */
+  const float *conv_pw1_w, *conv_pw1_b; /* conv_module.sequential.0.{weight,bias}   [2D,D,1] */
+  const float *conv_dw_w, *conv_dw_b;   /* conv_module.sequential.2.{weight,bias}   [D,1,K]  */
+  const float *conv_bn_w, *conv_bn_b;   /* conv_module.sequential.3.{weight,bias}            */
+  const float *conv_bn_rm, *conv_bn_rv; /* conv_module.sequential.3.running_{mean,var}       */
+  const float *conv_pw2_w, *conv_pw2_b; /* conv_module.sequential.5.{weight,bias}   [D,D,1]  */
+  const float *ffn2_ln_w, *ffn2_ln_b, *ffn2_w1, *ffn2_b1, *ffn2_w2, *ffn2_b2; /* ffn2.sequential.* */
+  const float *final_ln_w, *final_ln_b; /* final_layer_norm.{weight,bias}                    */
+} eec_layer_params;
+
+typedef struct eec_params {
+  const float *sub0_w, *sub0_b; /* conv_subsample.sequential.0  [D, n_mels, 3], [D] */
+  const float *sub1_w, *sub1_b; /* conv_subsample.sequential.1  [D, D, 3], [D]      */
+  const float* pe;              /* positional_encoder.pe        [max_len, 1, D]     */
+  const eec_layer_params* layers; /* HOST array of n_exits*layers_per_exit entries, exit-major */
+  const float* const* head_w;   /* HOST array of n_exits device pointers: linears.e.weight [V, D] */
+  const float* const* head_b;   /* HOST array of n_exits device pointers: linears.e.bias   [V]    */
+} eec_params;
+
+typedef struct eec_encoder eec_encoder;
+
+const char* eec_last_error(void);
+int eec_abi_version(void);
+
+/* T' = ((T-3)/2+1 - 3)/2 + 1 : frames after the two stride-2 convs (early_exit.py:24-48). */
+int eec_out_frames(int T);
+
+/* Replaces Early_conformer.__init__ (early_exit.py:567-615) for the encoder stack. */
+int eec_encoder_create(const eec_config* cfg, eec_encoder** out);
+void eec_encoder_destroy(eec_encoder* enc);
+
+/* Re-packs the fp32 parameters (fp16 hi/lo MFMA fragments, BatchNorm folded into the depthwise
+ * taps, conv weights transposed).  Call after load_state_dict / an optimizer step; eval-mode
+ * BatchNorm semantics (running statistics).  Asynchronous on `stream`. */
+int eec_encoder_pack(eec_encoder* enc, const eec_params* params, void* stream);
+
+size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T);
+
+/* Replaces Early_conformer.forward(src, lengths) (early_exit.py:617-634) in eval mode:
+ *   mel      [B, n_mels, T] fp32        lengths [B] int64 (device copy of the caller's tensor)
+ *   out      [E, B, T', V] fp32 log-probabilities (written in place, no torch.cat)
+ *   taps_opt [E, B, T', D] fp32 or NULL: pre-head activations after each exit group
+ *            (what full_conformer._encoder_(src, lengths, n) returns, early_exit.py:719-737)
+ *   stop_after: <0 = run everything; otherwise stop after that many sub-steps
+ *            (0 = stem, then per layer: ffn1, attention, conv, ffn2) -- test hook; the current
+ *            residual stream is then left in x_dbg_opt [B*T', D] if given. */
+int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T,
+                        int precision, float* out, float* taps_opt, void* workspace, size_t workspace_bytes,
+                        int stop_after, float* x_dbg_opt, void* stream);
+
+/* Replaces GreedyCTCDecoder.forward (util/beam_infer.py:9-24), batched over n_seq sequences:
+ *   logp [n_seq, Tq, V] fp32 -> tokens [n_seq, Tq] int32 (first counts[s] entries valid), counts [n_seq]. */
+int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32_t* tokens, int32_t* counts,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EEC_H_ */
