@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/sec of the early-exit Conformer encoder forward (all exits).
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "config 2"): the default 12-layer model
+(d_model 256, 8 heads, FFN 2048, depthwise K 31, 6 exits x 2 layers, vocab 256), batch 64 per GPU of
+synthetic log-normal mel [64, 80, 1027] (-> T' = 256), random-init weights from the portable
+generator.  One step = one ``Early_conformer.forward`` through the drop-in nn.Module: stem -> 12
+layers -> 6 CTC heads -> [6, 64, 256, 256] fp32 log-probs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
+  roofline     dominant kernel (fused feed-forward): algorithmic flop per launch / mean launch
+               duration from HIP events on the launch stream, vs the 2.5 PFLOP/s dense 16-bit MFMA peak
+  cpu_baseline the CPU oracle (oracle/conformer_ref.py, a port of the reference path) timed on
+               this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
+  modes        the same step in the faster, lower-precision operand modes (not the headline value)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_FLOPS = 2.5e15  # MI355X dense bf16/fp16 MFMA peak (MI355X_MICROARCH.md)
+
+CFG = dict(src_pad_idx=0, n_enc_exits=6, enc_voc_size=256, dec_voc_size=256, d_model=256, n_head=8, max_len=2000,
+           d_feed_forward=2048, n_enc_layers=2, features_length=80, drop_prob=0.1, depthwise_kernel_size=31)
+
+
+def flops_per_forward(B, T):
+    D, F, K, E, L, V, NM = 256, 2048, 31, 6, 2, 256, 80
+    T1 = (T - 3) // 2 + 1
+    Tq = (T1 - 3) // 2 + 1
+    mac_frame = E * L * (4 * D * F + 7 * D * D + K * D + 2 * Tq * D) + E * D * V + 3 * D * D + 3 * NM * D * T1 / Tq
+    return 2.0 * mac_frame * B * Tq, Tq
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=1027, help="mel frames per utterance")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "mixed", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-modes", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback; the CPU oracle is only the baseline leg)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from early_exit_transformer_amd import synth
+    from early_exit_transformer_amd.model import Early_conformer
+
+    B, T = args.batch, args.frames
+    model = Early_conformer(device=dev, **CFG).eval()
+    sd = synth.synth_state_dict(model.state_dict(), seed=0, style="init")
+    model.load_state_dict(sd)
+    model = model.to(dev)
+    model.precision = args.precision
+    mel = synth.synth_mel(B, CFG["features_length"], T, seed=rank).to(dev)
+    lengths = torch.full((B,), T, dtype=torch.int64)  # padded positions count as work; full-length batch
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run_steps(n):
+        out = None
+        for _ in range(n):
+            with torch.no_grad():
+                out = model(mel, lengths)
+            if dist is not None:
+                # data-path exchange of the sharded path: the per-exit scalar statistic that the
+                # summed per-exit CTC loss reduces to (6 x fp32), one RCCL all-reduce per step
+                stat = out[:, :, :, 0].mean(dim=(1, 2))
+                dist.all_reduce(stat)
+        return out
+
+    run_steps(args.warmup)
+    sync_all()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    sync_all()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * B * T * args.steps / dt
+    flop_fwd, Tq = flops_per_forward(B, T)
+
+    # ---- roofline of the dominant kernel (fused FFN), HIP events on the launch stream ----
+    roofline, kernel_ms = None, None
+    if rank == 0:
+        model.set_profiling(True)
+        run_steps(max(3, min(args.steps, 10)))
+        torch.cuda.synchronize()
+        prof = model.read_profile()
+        model.set_profiling(False)
+        ffn_ms, ffn_n = prof["ffn"]
+        M = B * Tq
+        ffn_flop = 4.0 * CFG["d_model"] * CFG["d_feed_forward"] * M
+        achieved = ffn_flop / (ffn_ms / ffn_n * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "ffn_kernel", "achieved": round(achieved, 2),
+                    "peak": MFMA_PEAK_FLOPS / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK_FLOPS, 4),
+                    "traffic": None, "avg_launch_us": round(ffn_ms / ffn_n * 1e3, 2), "launches": ffn_n,
+                    "flop_per_launch": ffn_flop}
+        tot = sum(v[0] for v in prof.values())
+        kernel_ms = {k: {"share": round(v[0] / tot, 4), "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "n": v[1]}
+                     for k, v in prof.items()}
+
+    # ---- the other operand modes (reported, never the headline) ----
+    modes = {}
+    if rank == 0 and world == 1 and not args.no_modes:
+        for prec in ("f16x3", "mixed", "f16"):
+            if prec == args.precision:
+                continue
+            model.precision = prec
+            run_steps(3)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t1
+            modes[prec] = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4),
+                           "frac_of_mfma_peak": round(flop_fwd * args.steps / d / MFMA_PEAK_FLOPS, 4)}
+        model.precision = args.precision
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import conformer_ref as R
+        # the box advertises every host core but grants this job a 16-core share: more threads only thrash
+        cores = min(len(os.sched_getaffinity(0)), 16)
+        torch.set_num_threads(cores)
+        ref = R.EarlyConformerRef(device="cpu", **CFG).eval()
+        ref.load_state_dict(sd)
+        bs = min(B, 8)
+        cmel = mel[:bs].cpu()
+        clen = lengths[:bs]
+        with torch.no_grad():
+            ref(cmel, clen)
+            t1 = time.perf_counter()
+            reps = 0
+            while reps < 3 or (time.perf_counter() - t1 < 10.0 and reps < 50):
+                ref(cmel, clen)
+                reps += 1
+            d = time.perf_counter() - t1
+        cpu = {"value": round(bs * T * reps / d, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+               "kind": "port", "sample": f"{reps} forwards of batch {bs} x {T} mel frames (same model, fp32, eval, no_grad)"}
+
+    if rank == 0:
+        line = {
+            "metric": "mel-frames/sec encoder forward (all exits), d_model=256 12-layer",
+            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": {"f16x3": "fp16x3 (hi/lo-split fp16 MFMA operands, fp32 accumulate)",
+                                                             "mixed": "fp16 FFN + fp16x3 projections", "f16": "fp16"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": f"early_conformer ctc 12-layer d_model=256 (6 exits x 2), batch {B}/GPU, mel [80 x {T}] -> T'={Tq}, log-normal synthetic mel, random-init weights (BASELINE.json configs[1])",
+                       "global_batch": B * world, "mel_frames": T, "parallelism": f"dp{world} (utterance-batch shards)",
+                       "precision_mode": args.precision, "parity_tolerance_logp": {"f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}[args.precision]},
+            "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
+            "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
+            "roofline": roofline, "cpu_baseline": cpu, "kernel_time": kernel_ms, "modes": modes,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -60,10 +60,19 @@ size_t frag_u4(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 128; 
 
 }  // namespace
 
+enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ, KC_GLU, KC_DW, KC_HEAD, KC_COUNT };
+
 struct eec_encoder {
   eec_config cfg;
   Arena arena;
   bool packed = false;
+  // optional per-kernel-class timing with HIP events on the launch stream (bench/roofline only)
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;       // pairs: start, stop
+  std::vector<int> ev_class;        // class of each recorded pair
+  size_t ev_used = 0;
+  double prof_ms[KC_COUNT] = {0};
+  long long prof_n[KC_COUNT] = {0};
   std::vector<PackedLayer> layers;
   float *sub_w1t, *sub_b1, *sub_w2t, *sub_b2, *pe;
   std::vector<uint4*> head_p;
@@ -195,6 +204,7 @@ int eec_encoder_create(const eec_config* cfg, eec_encoder** out) {
 
 void eec_encoder_destroy(eec_encoder* enc) {
   if (!enc) return;
+  for (hipEvent_t e : enc->ev) (void)hipEventDestroy(e);
   if (enc->arena.base) (void)hipFree(enc->arena.base);
   delete enc;
 }
@@ -282,11 +292,23 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
     return 0;
   };
 
+  // TIMED(class, launch-expression): brackets the launch with events when profiling is on
+#define TIMED(cls, expr)                                                        \
+  do {                                                                          \
+    const bool _p = enc->profiling && (enc->ev_used + 1) * 2 <= enc->ev.size(); \
+    if (_p) EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2], st));             \
+    EEC_HIP(expr);                                                              \
+    if (_p) {                                                                   \
+      EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2 + 1], st));               \
+      enc->ev_class[enc->ev_used++] = (cls);                                    \
+    }                                                                           \
+  } while (0)
+
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
   {
     SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1t, enc->sub_b1, enc->sub_w2t, enc->sub_b2, enc->pe, ws.mid, ws.x};
-    EEC_HIP(launch_subsample(a, st));
+    TIMED(KC_STEM, launch_subsample(a, st));
   }
   ++step;
   if (done()) return finish_dbg();
@@ -296,45 +318,79 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
       {
         FfnArgs a{ws.x, M, c.d_ff, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr};
-        EEC_HIP(launch_ffn(a, np_ffn, st));
+        TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
       ++step;
       if (done()) return finish_dbg();
       {
         QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
-        EEC_HIP(launch_qkv(a, np_o, st));
+        TIMED(KC_QKV, launch_qkv(a, np_o, st));
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
-        EEC_HIP(launch_attention(at, np_o, st));
+        TIMED(KC_ATTN, launch_attention(at, np_o, st));
         ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
-        EEC_HIP(launch_proj_residual(pr, np_o, st));
+        TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
       }
       ++step;
       if (done()) return finish_dbg();
       {
         GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
-        EEC_HIP(launch_pw1_glu(ga, np_o, st));
+        TIMED(KC_GLU, launch_pw1_glu(ga, np_o, st));
         DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-        EEC_HIP(launch_dwconv(da, np_o, st));
+        TIMED(KC_DW, launch_dwconv(da, np_o, st));
         ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.conv_pw2_p, L.conv_pw2_b};
-        EEC_HIP(launch_proj_residual(pr, np_o, st));
+        TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
       }
       ++step;
       if (done()) return finish_dbg();
       {
         FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b};
-        EEC_HIP(launch_ffn(a, np_ffn, st));
+        TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
       ++step;
       if (done()) return finish_dbg();
     }
     if (out) {
       HeadArgs h{ws.x, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
-      EEC_HIP(launch_head(h, np_o, st));
+      TIMED(KC_HEAD, launch_head(h, np_o, st));
     }
     if (taps_opt)
       EEC_HIP(hipMemcpyAsync(taps_opt + (size_t)e * M * D, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
   }
   return finish_dbg();
+}
+
+int eec_encoder_set_profiling(eec_encoder* enc, int enable, int max_launches) {
+  if (!enc) return fail(EEC_ERR_BAD_ARG, "null argument");
+  for (hipEvent_t e : enc->ev) (void)hipEventDestroy(e);
+  enc->ev.clear();
+  enc->ev_class.clear();
+  enc->ev_used = 0;
+  for (int i = 0; i < KC_COUNT; ++i) enc->prof_ms[i] = 0, enc->prof_n[i] = 0;
+  enc->profiling = enable != 0;
+  if (enc->profiling) {
+    if (max_launches <= 0) max_launches = 4096;
+    enc->ev.resize((size_t)max_launches * 2);
+    enc->ev_class.assign(max_launches, 0);
+    for (auto& e : enc->ev) EEC_HIP(hipEventCreate(&e));
+  }
+  return 0;
+}
+
+int eec_encoder_profile_read(eec_encoder* enc, double* ms_by_class, long long* launches_by_class, int n_classes) {
+  if (!enc || !ms_by_class || !launches_by_class) return fail(EEC_ERR_BAD_ARG, "null argument");
+  for (size_t i = 0; i < enc->ev_used; ++i) {
+    EEC_HIP(hipEventSynchronize(enc->ev[2 * i + 1]));
+    float ms = 0.f;
+    EEC_HIP(hipEventElapsedTime(&ms, enc->ev[2 * i], enc->ev[2 * i + 1]));
+    enc->prof_ms[enc->ev_class[i]] += ms;
+    enc->prof_n[enc->ev_class[i]] += 1;
+  }
+  enc->ev_used = 0;
+  for (int i = 0; i < n_classes && i < KC_COUNT; ++i) {
+    ms_by_class[i] = enc->prof_ms[i];
+    launches_by_class[i] = enc->prof_n[i];
+  }
+  return 0;
 }
 
 int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32_t* tokens, int32_t* counts,

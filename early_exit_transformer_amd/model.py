@@ -110,6 +110,19 @@ class _HipEncoderMixin:
         capi.check(lib.eec_encoder_pack(self._enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
         self._packed_key = key
 
+    # -- measurement hook -----------------------------------------------------
+    def set_profiling(self, enable: bool, max_launches: int = 8192) -> None:
+        if self._enc is None:
+            raise RuntimeError("run one forward first (the encoder handle is created lazily)")
+        capi.check(capi.load().eec_encoder_set_profiling(self._enc, int(enable), max_launches), "set_profiling")
+
+    def read_profile(self) -> Dict[str, Tuple[float, int]]:
+        """{kernel class: (total ms, launches)} of the launches recorded since set_profiling(True)."""
+        n = len(capi.KERNEL_CLASSES)
+        ms, cnt = (C.c_double * n)(), (C.c_longlong * n)()
+        capi.check(capi.load().eec_encoder_profile_read(self._enc, ms, cnt, n), "profile_read")
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(capi.KERNEL_CLASSES)}
+
     # -- forward ------------------------------------------------------------
     def _workspace(self, B: int, T: int, device: torch.device) -> Tensor:
         k = (B, T, device.index or 0)

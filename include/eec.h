@@ -106,6 +106,14 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
                         int precision, float* out, float* taps_opt, void* workspace, size_t workspace_bytes,
                         int stop_after, float* x_dbg_opt, void* stream);
 
+/* Measurement hook (no reference counterpart; the reference has no profiler hooks):
+ * when enabled, every kernel launch of eec_encoder_forward is bracketed by hipEventRecord on the
+ * launch stream; eec_encoder_profile_read synchronises the recorded events and returns the summed
+ * milliseconds and launch counts per kernel class, index = EEC_KC_*. */
+enum { EEC_KC_STEM = 0, EEC_KC_FFN, EEC_KC_QKV, EEC_KC_ATTN, EEC_KC_PROJ, EEC_KC_GLU, EEC_KC_DW, EEC_KC_HEAD, EEC_KC_COUNT };
+int eec_encoder_set_profiling(eec_encoder* enc, int enable, int max_launches);
+int eec_encoder_profile_read(eec_encoder* enc, double* ms_by_class, long long* launches_by_class, int n_classes);
+
 /* Replaces GreedyCTCDecoder.forward (util/beam_infer.py:9-24), batched over n_seq sequences:
  *   logp [n_seq, Tq, V] fp32 -> tokens [n_seq, Tq] int32 (first counts[s] entries valid), counts [n_seq]. */
 int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32_t* tokens, int32_t* counts,

@@ -1,0 +1,240 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP encoder, called through the drop-in
+nn.Module -> ctypes -> C-ABI, against the CPU oracle and the committed golden fixtures.
+
+Tolerances (max |delta log-prob| vs the fp32 reference path, stated per operand mode):
+    f16x3  1e-3   (north_star's tolerance; measured ~2.5e-4 on the 12-layer model)
+    mixed  2.5e-3 (measured ~1.1e-3)
+    f16    6e-3   (measured ~2.9e-3)
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import base_kwargs, load_golden
+from early_exit_transformer_amd import synth
+from early_exit_transformer_amd.model import Early_conformer, full_conformer, greedy_ctc
+from oracle import conformer_ref as R
+
+pytestmark = pytest.mark.gpu
+TOL = {"f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}
+
+
+def make_pair(kw, seed, style="trained", head_scale=1.0):
+    ref = R.EarlyConformerRef(**kw).eval()
+    sd = synth.synth_state_dict(ref.state_dict(), seed=seed, style=style, head_scale=head_scale)
+    ref.load_state_dict(sd)
+    gpu = Early_conformer(**{**kw, "device": "cuda"}).eval()
+    gpu.load_state_dict(sd, strict=True)
+    return ref, gpu.cuda()
+
+
+def run_gpu(model, mel, lens, prec="f16x3"):
+    model.precision = prec
+    with torch.no_grad():
+        out = model(mel.cuda(), lens)
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def test_native_library_is_loaded():
+    from early_exit_transformer_amd import capi
+    lib = capi.load()
+    assert lib.eec_abi_version() == 1
+    assert any("libeec.so" in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "mixed", "f16"])
+@pytest.mark.parametrize("name", ["small", "small_h4_k7", "config1"])
+def test_golden_logprobs(name, prec):
+    """Committed fixtures made by the reference's own Early_conformer class body (make_golden.py)."""
+    z, kw = load_golden(name)
+    gpu = Early_conformer(**{**kw, "device": "cuda"}).eval()
+    gpu.load_state_dict(synth.synth_state_dict(gpu.state_dict(), seed=int(z["seed"]), style=str(z["style"]),
+                                               head_scale=float(z["head_scale"])))
+    gpu = gpu.cuda()
+    mel = synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"]))
+    out = run_gpu(gpu, mel, torch.from_numpy(z["lengths"]), prec)
+    assert out.shape[:2] == z["logp"].shape[:2] and not torch.isnan(out).any()
+    err = np.abs(out[:, :, ::int(z["stride"])].numpy() - z["logp"]).max()
+    assert err < TOL[prec], f"{name}/{prec}: max|dlogp| {err:.3e}"
+    # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only)
+    assert np.allclose([out[e].double().sum().item() for e in range(out.size(0))], z["checksum"],
+                       rtol=0, atol=TOL[prec] * out[0].numel() * 0.05)
+
+
+def test_golden_greedy_decode_exact():
+    """Greedy CTC (util/beam_infer.py:9-24) on peaky heads: token sequences identical to the reference's for
+    every (exit, utterance) whose frames all have a top-2 margin above twice the log-prob tolerance."""
+    z, kw = load_golden("config1_peaky")
+    gpu = Early_conformer(**{**kw, "device": "cuda"}).eval()
+    gpu.load_state_dict(synth.synth_state_dict(gpu.state_dict(), seed=int(z["seed"]), style=str(z["style"]),
+                                               head_scale=float(z["head_scale"])))
+    gpu = gpu.cuda()
+    mel = synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"]))
+    gpu.precision = "f16x3"
+    with torch.no_grad():
+        out = gpu(mel.cuda(), torch.from_numpy(z["lengths"]))
+        got = gpu.greedy_decode(out)
+    E, B = z["greedy_counts"].shape
+    flat, pos, compared = z["greedy_flat"].tolist(), 0, 0
+    safe = (z["margin"] > 2 * TOL["f16x3"]).all(axis=-1)  # [E,B]
+    frame_ok = z["margin"] > 2 * TOL["f16x3"]
+    am = out.argmax(-1).cpu().numpy()
+    assert (am[frame_ok] == z["argmax"][frame_ok]).all(), "argmax differs on a frame with a safe margin"
+    for e in range(E):
+        for b in range(B):
+            n = int(z["greedy_counts"][e, b])
+            want = flat[pos:pos + n]
+            pos += n
+            if safe[e, b]:
+                assert got[e][b] == want, f"exit {e} utt {b}"
+                compared += 1
+    assert compared >= E * B // 2, f"only {compared}/{E*B} sequences had safe margins"
+
+
+def test_greedy_kernel_bit_exact_on_same_logprobs():
+    """Integer path: the decode kernel vs the oracle decoder on the SAME log-probs, incl. ties and ragged T'."""
+    torch.manual_seed(0)
+    for n, t, v in [(5, 1, 32), (3, 64, 256), (4, 65, 64), (2, 333, 256), (7, 128, 32)]:
+        lp = torch.log_softmax(torch.randn(n, t, v) * 3, -1)
+        lp[0, : t // 2] = lp[0, :1]  # long runs of repeats
+        lp[-1, :, 0] = 1.0  # all blank
+        if t > 3:
+            lp[1, 2, 5] = lp[1, 2].max()  # an exact tie -> lowest index wins, as torch.argmax
+        tokens, counts = greedy_ctc(lp.cuda())
+        tokens, counts = tokens.cpu(), counts.cpu()
+        for i in range(n):
+            assert tokens[i, : counts[i]].tolist() == R.greedy_ctc(lp[i])
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_every_substep_against_oracle(prec):
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=2, d_feed_forward=512)
+    ref, gpu = make_pair(kw, seed=4)
+    mel, lens = synth.synth_mel(3, 80, 203, seed=4), torch.tensor([203, 150, 99])
+    with torch.no_grad():
+        steps = R.trace_substeps(ref, mel, lens)
+    gpu.precision = prec
+    for k, want in enumerate(steps):
+        with torch.no_grad():
+            x = gpu._run_encoder(mel.cuda(), lens, want_out=False, stop_after=k, want_x=True)[2].cpu()
+        scale = want.abs().max().item()
+        err = (x - want).abs().max().item()
+        assert err < (2e-4 if prec == "f16x3" else 2e-3) * max(scale, 1.0), f"sub-step {k}: {err:.3e} (scale {scale:.2f})"
+
+
+@pytest.mark.parametrize("B,T,lens", [
+    (1, 7, [7]),                     # T' = 1: the shortest legal input
+    (1, 131, [131]),                 # single utterance, one partial row tile
+    (5, 403, [403, 402, 300, 77, 5]),  # T' = 99: not a multiple of 32; M = 495 not a multiple of 64; len -> 1
+    (2, 1100, [1100, 640]),          # T' = 274 > 256: two key chunks in the attention kernel
+    (3, 259, [259, 259, 259]),       # no padding at all
+])
+def test_ragged_shapes(B, T, lens):
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256)
+    ref, gpu = make_pair(kw, seed=9)
+    mel, lt = synth.synth_mel(B, 80, T, seed=9), torch.tensor(lens)
+    with torch.no_grad():
+        want = ref(mel, lt)
+    got = run_gpu(gpu, mel, lt)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < TOL["f16x3"]
+    assert torch.allclose(got.exp().sum(-1), torch.ones(got.shape[:-1]), atol=1e-4)
+
+
+@pytest.mark.parametrize("over", [dict(n_head=4), dict(depthwise_kernel_size=7), dict(depthwise_kernel_size=1),
+                                  dict(d_feed_forward=128), dict(dec_voc_size=32), dict(dec_voc_size=160),
+                                  dict(n_enc_exits=1, n_enc_layers=3), dict(features_length=40)])
+def test_config_surface(over):
+    """--n_heads / --depthwise_kernel_size / --d_feed_forward / vocab / --n_enc_exits / --n_enc_layers_per_exit / --n_mels."""
+    kw = base_kwargs(**{**dict(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256), **over})
+    ref, gpu = make_pair(kw, seed=13)
+    nm = kw["features_length"]
+    mel, lens = synth.synth_mel(2, nm, 179, seed=13), torch.tensor([179, 120])
+    with torch.no_grad():
+        want = ref(mel, lens)
+    assert (run_gpu(gpu, mel, lens) - want).abs().max().item() < TOL["f16x3"]
+
+
+def test_full_conformer_encoder_taps_golden():
+    """config 5 substitute: full_conformer._encoder_(src, lengths, n) (early_exit.py:719-737), fixture from the
+    reference's own full_conformer."""
+    z, kw = load_golden("full_conformer_taps")
+    kw.pop("src_pad_idx"), kw.pop("device")
+    fc = full_conformer(trg_pad_idx=126, n_dec_layers=1, device="cuda", **kw).eval()
+    enc_keys = {k: v for k, v in fc.state_dict().items()
+                if k.split(".")[0] in ("conv_subsample", "linears_1", "positional_encoder_1", "conformer")}
+    fc.load_state_dict(synth.synth_state_dict(enc_keys, seed=int(z["seed"]), style="trained"), strict=False)
+    fc = fc.cuda()
+    mel, lens = synth.synth_mel(1, 80, int(z["T"]), seed=int(z["seed"])), torch.tensor([int(z["T"])])
+    with torch.no_grad():
+        for n in (1, 2):
+            tap = fc._encoder_(mel.cuda(), lens, n).cpu().numpy()
+            assert np.abs(tap - z["taps"][n - 1]).max() < 1e-3
+        dec, enc = fc(mel.cuda(), lens, torch.tensor([[1, 5, 9, 2]]).cuda())
+    assert dec.shape == (2, 1, 4, 256) and enc.shape == (2, 1, 50, 256)
+
+
+def test_reload_weights_repacks():
+    kw = base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128)
+    ref, gpu = make_pair(kw, seed=1)
+    mel, lens = synth.synth_mel(2, 80, 99, seed=1), torch.tensor([99, 64])
+    a = run_gpu(gpu, mel, lens)
+    sd2 = synth.synth_state_dict(ref.state_dict(), seed=2, style="trained")
+    gpu.load_state_dict(sd2)
+    ref.load_state_dict(sd2)
+    b = run_gpu(gpu, mel, lens)
+    with torch.no_grad():
+        want = ref(mel, lens)
+    assert (b - want).abs().max().item() < 1e-3 and (a - b).abs().max().item() > 1e-2
+
+
+def test_error_paths():
+    gpu = Early_conformer(**base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128, max_len=40, device="cuda")).eval().cuda()
+    with pytest.raises(ValueError):
+        gpu(torch.zeros(1, 81, 99).cuda(), torch.tensor([99]))
+    with pytest.raises(RuntimeError, match="max_len"):
+        gpu(torch.zeros(1, 80, 403).cuda(), torch.tensor([403]))  # T' = 99 > 40
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        gpu(torch.zeros(1, 80, 99), torch.tensor([99]))
+    with pytest.raises(RuntimeError, match="unsupported|256"):
+        Early_conformer(**base_kwargs(d_model=128, n_head=4, device="cuda")).eval().cuda()(torch.zeros(1, 80, 99).cuda(), torch.tensor([99]))
+    gpu.train()
+    with pytest.raises(NotImplementedError):
+        gpu(torch.zeros(1, 80, 99).cuda(), torch.tensor([99]))
+
+
+class TestFullSize:
+    """BASELINE.json configs[1] (B=64, T=1027): size-independent properties instead of a CPU run."""
+
+    @pytest.fixture(scope="class")
+    def setup(self):
+        kw = base_kwargs()
+        ref, gpu = make_pair(kw, seed=0, style="trained")
+        mel = synth.synth_mel(64, 80, 1027, seed=0)
+        lens = synth.synth_lengths(64, 1027, seed=0)
+        out = run_gpu(gpu, mel, lens)
+        return ref, gpu, mel, lens, out
+
+    def test_normalised_and_finite(self, setup):
+        _, _, _, _, out = setup
+        assert out.shape == (6, 64, 256, 256) and torch.isfinite(out).all()
+        assert torch.allclose(out.exp().sum(-1), torch.ones(6, 64, 256), atol=2e-4)
+
+    def test_deterministic(self, setup):
+        _, gpu, mel, lens, out = setup
+        assert torch.equal(run_gpu(gpu, mel, lens), out)
+
+    def test_utterances_are_independent(self, setup):
+        """Batch sharding premise: an utterance's result does not depend on its batch neighbours."""
+        _, gpu, mel, lens, out = setup
+        sub = run_gpu(gpu, mel[40:44], lens[40:44])
+        assert torch.equal(sub, out[:, 40:44])
+
+    def test_subset_against_oracle(self, setup):
+        ref, _, mel, lens, out = setup
+        idx = [0, 17, 63]
+        with torch.no_grad():
+            # the reference mask needs max(lengths) == T inside the sub-batch: utterance 0 is full length
+            want = ref(mel[idx], lens[idx])
+        assert (out[:, idx] - want).abs().max().item() < TOL["f16x3"]

@@ -1,0 +1,118 @@
+"""CPU tests of the host side: the C-ABI library loads and exports everything include/eec.h declares
+(no compute calls without a GPU), argument validation, loud failure without a HIP device, and the
+world_size-2 sharded-loss path over gloo."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, base_kwargs
+from early_exit_transformer_amd import capi, parallel, synth
+from early_exit_transformer_amd.build import LIB_PATH
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB_PATH):
+        from early_exit_transformer_amd.build import build_library
+        build_library()
+    return capi.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "eec.h")).read()
+    declared = set(re.findall(r"\b(eec_[a-z_0-9]+)\s*\(", header))
+    declared -= {"eec_encoder"}  # the opaque struct tag
+    assert declared, "no prototypes parsed"
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
+    assert set(capi.EXPORTS) == declared
+    assert lib.eec_abi_version() == 1
+
+
+def test_out_frames_matches_conv_arithmetic(lib):
+    for T in (7, 8, 10, 11, 131, 1027, 2051, 8003):
+        t1 = (T - 3) // 2 + 1
+        assert lib.eec_out_frames(T) == (t1 - 3) // 2 + 1
+    assert lib.eec_out_frames(6) == 0
+    assert lib.eec_out_frames(1027) == 256
+
+
+@pytest.mark.parametrize("field,value,code", [("d_model", 128, 10002), ("n_heads", 3, 10001), ("d_ff", 100, 10002),
+                                              ("dw_kernel", 32, 10002), ("dw_kernel", 33, 10002), ("vocab", 300, 10002),
+                                              ("n_exits", 0, 10001)])
+def test_create_rejects_unsupported_configs_before_touching_the_gpu(lib, field, value, code):
+    cfg = capi.EecConfig(256, 8, 2048, 31, 6, 2, 80, 256, 2000)
+    setattr(cfg, field, value)
+    h = C.c_void_p()
+    assert lib.eec_encoder_create(C.byref(cfg), C.byref(h)) == code
+    assert lib.eec_last_error()
+
+
+def test_product_module_has_no_cpu_path():
+    from early_exit_transformer_amd.model import Early_conformer
+    from early_exit_transformer_amd.conformer import Conformer
+    m = Early_conformer(**base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128)).eval()
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        m(torch.zeros(1, 80, 64), torch.tensor([64]))
+    with pytest.raises(RuntimeError, match="parameter container"):
+        Conformer(256, 8, 128, 1, 31)(torch.zeros(1, 4, 256), torch.tensor([4]))
+    import early_exit_transformer_amd.model as pm
+    src = open(pm.__file__).read()
+    assert "oracle" not in src.replace("oracle/", "") or "import oracle" not in src
+
+
+def test_shard_range_partitions():
+    for n in (1, 7, 64, 513):
+        for world in (1, 2, 3, 8):
+            spans = [parallel.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _rank_main(rank, world, port, q):
+    from oracle import conformer_ref as R
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=128)
+        m = R.EarlyConformerRef(**kw).eval()
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=0, style="trained"))
+        B, T = 5, 131  # uneven shards: 3 + 2
+        mel = synth.synth_mel(B, 80, T, seed=0)
+        lens = torch.tensor([131, 120, 111, 131, 80])  # every shard holds a full-length utterance (a3 invariant)
+        tgt, tl = synth.synth_targets(B, 10, 256, seed=0)
+        ctc = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)
+
+        def exit_losses(lp, t, l):
+            il = torch.full((lp.size(1),), lp.size(2), dtype=torch.long)
+            return torch.stack([ctc(lp[e].permute(1, 0, 2), t, il, l) for e in range(lp.size(0))])
+
+        lo, hi = parallel.shard_range(B, rank, world)
+        with torch.no_grad():
+            local = exit_losses(m(mel[lo:hi], lens[lo:hi]), tgt[lo:hi], tl[lo:hi])
+            combined = parallel.combine_exit_losses(local, hi - lo)
+            if rank == 0:
+                full = exit_losses(m(mel, lens), tgt, tl)
+                q.put((combined.tolist(), full.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_sharded_exit_loss_equals_global_batch():
+    """N>1 path: utterance shards + one all-reduce reproduce the single-process batch-mean CTC loss."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    combined, full = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert combined == pytest.approx(full, rel=2e-5, abs=2e-5)
