@@ -159,7 +159,7 @@ int check_cfg(const eec_config& c) {
   if (c.n_heads <= 0 || kD % c.n_heads) return fail(EEC_ERR_BAD_ARG, "n_heads must divide d_model");
   const int dh = kD / c.n_heads;
   if (dh != 32 && dh != 64) return fail(EEC_ERR_UNSUPPORTED, "head dim must be 32 or 64");
-  if (c.d_ff <= 0 || c.d_ff % 128) return fail(EEC_ERR_UNSUPPORTED, "d_ff must be a positive multiple of 128");
+  if (c.d_ff <= 0 || c.d_ff % 32) return fail(EEC_ERR_UNSUPPORTED, "d_ff must be a positive multiple of 32");
   if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1))
     return fail(EEC_ERR_UNSUPPORTED, "depthwise kernel must be odd and <= 31");
   if (c.vocab <= 0 || c.vocab > 256 || c.vocab % 32) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 32, <= 256");
@@ -222,30 +222,30 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     PackedLayer& L = enc->layers[i];
     EEC_HIP(cp(L.ffn1_ln_w, s.ffn1_ln_w, D));
     EEC_HIP(cp(L.ffn1_ln_b, s.ffn1_ln_b, D));
-    EEC_HIP(cp(L.ffn1_b1, s.ffn1_b1, F));
+    EEC_HIP(launch_scale_copy(s.ffn1_b1, L.ffn1_b1, F, kLog2e, st));
     EEC_HIP(cp(L.ffn1_b2, s.ffn1_b2, D));
-    EEC_HIP(launch_pack_frags(s.ffn1_w1, F, D, L.ffn1_w1p, st));
-    EEC_HIP(launch_pack_frags(s.ffn1_w2, D, F, L.ffn1_w2p, st));
+    EEC_HIP(launch_pack_frags(s.ffn1_w1, F, D, L.ffn1_w1p, kLog2e, st));
+    EEC_HIP(launch_pack_frags(s.ffn1_w2, D, F, L.ffn1_w2p, 1.0f / kLog2e, st));
     EEC_HIP(cp(L.attn_ln_w, s.attn_ln_w, D));
     EEC_HIP(cp(L.attn_ln_b, s.attn_ln_b, D));
     EEC_HIP(cp(L.attn_in_b, s.attn_in_b, 3 * D));
     EEC_HIP(cp(L.attn_out_b, s.attn_out_b, D));
-    EEC_HIP(launch_pack_frags(s.attn_in_w, 3 * D, D, L.attn_in_p, st));
-    EEC_HIP(launch_pack_frags(s.attn_out_w, D, D, L.attn_out_p, st));
+    EEC_HIP(launch_pack_frags(s.attn_in_w, 3 * D, D, L.attn_in_p, 1.0f, st));
+    EEC_HIP(launch_pack_frags(s.attn_out_w, D, D, L.attn_out_p, 1.0f, st));
     EEC_HIP(cp(L.conv_ln_w, s.conv_ln_w, D));
     EEC_HIP(cp(L.conv_ln_b, s.conv_ln_b, D));
     EEC_HIP(cp(L.conv_pw1_b, s.conv_pw1_b, 2 * D));
     EEC_HIP(cp(L.conv_pw2_b, s.conv_pw2_b, D));
-    EEC_HIP(launch_pack_frags(s.conv_pw1_w, 2 * D, D, L.conv_pw1_p, st));
-    EEC_HIP(launch_pack_frags(s.conv_pw2_w, D, D, L.conv_pw2_p, st));
+    EEC_HIP(launch_pack_frags(s.conv_pw1_w, 2 * D, D, L.conv_pw1_p, 1.0f, st));
+    EEC_HIP(launch_pack_frags(s.conv_pw2_w, D, D, L.conv_pw2_p, 1.0f, st));
     EEC_HIP(launch_fold_dw(s.conv_dw_w, s.conv_dw_b, s.conv_bn_w, s.conv_bn_b, s.conv_bn_rm, s.conv_bn_rv,
                            c.dw_kernel, L.dw_wfold, L.dw_bfold, st));
     EEC_HIP(cp(L.ffn2_ln_w, s.ffn2_ln_w, D));
     EEC_HIP(cp(L.ffn2_ln_b, s.ffn2_ln_b, D));
-    EEC_HIP(cp(L.ffn2_b1, s.ffn2_b1, F));
+    EEC_HIP(launch_scale_copy(s.ffn2_b1, L.ffn2_b1, F, kLog2e, st));
     EEC_HIP(cp(L.ffn2_b2, s.ffn2_b2, D));
-    EEC_HIP(launch_pack_frags(s.ffn2_w1, F, D, L.ffn2_w1p, st));
-    EEC_HIP(launch_pack_frags(s.ffn2_w2, D, F, L.ffn2_w2p, st));
+    EEC_HIP(launch_pack_frags(s.ffn2_w1, F, D, L.ffn2_w1p, kLog2e, st));
+    EEC_HIP(launch_pack_frags(s.ffn2_w2, D, F, L.ffn2_w2p, 1.0f / kLog2e, st));
     EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
   }
@@ -255,7 +255,7 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
   EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
   EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
   for (int e = 0; e < c.n_exits; ++e) {
-    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], st));
+    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
     EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
   }
   enc->packed = true;

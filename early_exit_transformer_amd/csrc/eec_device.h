@@ -88,6 +88,31 @@ __device__ __forceinline__ hl_t split_hl(float x) {
     (LO)[idx] = _t.lo;                    \
   } while (0)
 
+// packed hi/lo split of two values (6 VALU per pair in the split form).
+struct hl2_t {
+  h2 hi, lo;
+};
+// NP == 3: hi = rtz(x) (never overflows to inf), lo = rtz(x - hi): x = hi + lo to ~2^-21.
+// NP == 1: there is no lo plane, so hi must be round-to-nearest (truncation doubles the error).
+template <int NP>
+__device__ __forceinline__ hl2_t split2(float a, float b) {
+  hl2_t r;
+  if (NP == 3) {
+    r.hi = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
+    r.lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a - (float)r.hi[0], b - (float)r.hi[1]));
+  } else {
+    r.hi[0] = to_half_sat(a);
+    r.hi[1] = to_half_sat(b);
+    r.lo = r.hi;
+  }
+  return r;
+}
+// SiLU in the exp2 domain: u = log2(e) * x  ->  u / (1 + 2^-u) = log2(e) * silu(x).
+// (log2(e) is folded into W1/b1 and 1/log2(e) into W2 at pack time.)  4 VALU, 2 transcendental.
+__device__ __forceinline__ float silu_exp2(float u) {
+  return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
@@ -168,6 +193,98 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[MT][NT], const char* ld
   }
 }
 
+// ---------------------------------------------------------------------------
+// Register ring of weight fragments: the first PF k-steps of a stage are loaded by the caller
+// one stage AHEAD (so no stage starts with an empty pipeline), the stage refills it PF ahead.
+// w_lane points at fragment (nt, s0), plane 0, this lane; consecutive k-steps are 128 uint4 apart.
+// ---------------------------------------------------------------------------
+template <int NP, int PF>
+struct WRing {
+  uint4 q[PF][(NP == 3) ? 2 : 1];
+};
+
+template <int NP, int PF>
+__device__ __forceinline__ void ring_fill(WRing<NP, PF>& r, const uint4* __restrict__ w_lane, int steps_avail) {
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < steps_avail) {
+      r.q[p][0] = w_lane[(size_t)p * 128];
+      if (NP == 3) r.q[p][(NP == 3) ? 1 : 0] = w_lane[(size_t)p * 128 + 64];
+    }
+  __builtin_amdgcn_sched_barrier(0);  // keep these loads HERE: one stage ahead of their consumer
+}
+
+// acc[2][1] += Act[64 rows][16*KS] (LDS planes) x Wfrag stream; MT = 2 row tiles, one 32-wide n-tile.
+// Software pipeline, pinned with sched_barrier(0) at every k-step boundary (hipcc otherwise sinks
+// the prefetch loads down to their first use and every step pays a full L2 round trip):
+//   step s:  ds_read A(s+1)  |  MFMAs of step s from ring slot s%PF  |  global_load W(s+PF) -> slot s%PF
+template <int NP, int KS, bool SWAP, int PF>
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
+                                          const uint4* __restrict__ w_lane, WRing<NP, PF>& r) {
+  constexpr int LO = (NP == 3) ? 1 : 0;
+  h8 ah[2][2], al[2][2];  // [buffer][mt]
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
+    if (NP == 3) al[0][mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes);
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
+        if (NP == 3) al[nxt][mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + (s + 1) * 32);
+      }
+    }
+    const h8 bh = __builtin_bit_cast(h8, r.q[s % PF][0]);
+    const h8 bl = __builtin_bit_cast(h8, r.q[s % PF][LO]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      if (!SWAP) {
+        if (NP == 3) {
+          acc[mt][0] = mfma16(al[cur][mt], bh, acc[mt][0]);
+          acc[mt][0] = mfma16(ah[cur][mt], bl, acc[mt][0]);
+        }
+        acc[mt][0] = mfma16(ah[cur][mt], bh, acc[mt][0]);
+      } else {
+        if (NP == 3) {
+          acc[mt][0] = mfma16(bh, al[cur][mt], acc[mt][0]);
+          acc[mt][0] = mfma16(bl, ah[cur][mt], acc[mt][0]);
+        }
+        acc[mt][0] = mfma16(bh, ah[cur][mt], acc[mt][0]);
+      }
+    }
+    if (s + PF < KS) {
+      r.q[s % PF][0] = w_lane[(size_t)(s + PF) * 128];
+      if (NP == 3) r.q[s % PF][LO] = w_lane[(size_t)(s + PF) * 128 + 64];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// Same product with a runtime k-step count and no ring (ragged tails only).
+template <int NP, bool SWAP>
+__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
+                                           const uint4* __restrict__ w_lane, int ks) {
+  for (int s = 0; s < ks; ++s) {
+    const h8 bh = __builtin_bit_cast(h8, w_lane[(size_t)s * 128]);
+    h8 bl = bh;
+    if (NP == 3) bl = __builtin_bit_cast(h8, w_lane[(size_t)s * 128 + 64]);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
+      if (NP == 3) {
+        const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
+        acc[mt][0] = SWAP ? mfma16(bh, al, acc[mt][0]) : mfma16(al, bh, acc[mt][0]);
+        acc[mt][0] = SWAP ? mfma16(bl, ah, acc[mt][0]) : mfma16(ah, bl, acc[mt][0]);
+      }
+      acc[mt][0] = SWAP ? mfma16(bh, ah, acc[mt][0]) : mfma16(ah, bh, acc[mt][0]);
+    }
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -183,7 +300,7 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 // Each wave handles 16 rows; a row is one coalesced 1 KiB float4 load.
 // ---------------------------------------------------------------------------
 // x fp32 [M][256] -> (optional LayerNorm) -> hi/lo planes.
-template <int NP, bool DO_LN>
+template <int NP, bool DO_LN, int RPW = 16>
 __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* __restrict__ x, int row0, int M,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta) {
@@ -194,8 +311,8 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
     bt = ((const float4*)beta)[lane];
   }
 #pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int rl = w * 16 + i, row = row0 + rl;
+  for (int i = 0; i < RPW; ++i) {
+    const int rl = w * RPW + i, row = row0 + rl;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < M) v = ((const float4*)(x + (size_t)row * kD))[lane];
     if (DO_LN) {
@@ -209,11 +326,9 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
       v.w = dw * rs * g.w + bt.w;
       if (row >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    const hl2_t s0 = split2<NP>(v.x, v.y), s1 = split2<NP>(v.z, v.w);
     h4 hi, lo;
-    EEC_SPLIT(v.x, hi, lo, 0);
-    EEC_SPLIT(v.y, hi, lo, 1);
-    EEC_SPLIT(v.z, hi, lo, 2);
-    EEC_SPLIT(v.w, hi, lo, 3);
+    hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
     *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
     if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
   }

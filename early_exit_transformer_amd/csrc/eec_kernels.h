@@ -8,9 +8,9 @@ struct FfnArgs {
   float* x;  // [M][256] fp32, updated in place
   int M, F;
   const float *ln_g, *ln_b;
-  const uint4* w1p;  // packed [F][256]
-  const float* b1;
-  const uint4* w2p;  // packed [256][F]
+  const uint4* w1p;  // packed log2(e) * W1 [F][256]
+  const float* b1;   // log2(e) * b1
+  const uint4* w2p;  // packed W2 / log2(e) [256][F]
   const float* b2;
   const float *fin_g, *fin_b;  // optional final LayerNorm (nullptr = none)
 };
@@ -83,7 +83,8 @@ struct SubsampleArgs {
 hipError_t launch_subsample(const SubsampleArgs& a, hipStream_t st);
 
 // weight packing (device -> device)
-hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, hipStream_t st);  // W[N][K] -> fragments
+hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // scale*W[N][K] -> fragments
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
                           const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,
                           hipStream_t st);

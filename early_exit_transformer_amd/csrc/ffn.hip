@@ -3,77 +3,109 @@
 //
 //     x <- [LN_final]( 0.5 * ( W2 . silu( W1 . LN(x) + b1 ) + b2 ) + x )
 //
-// One workgroup = 64 rows of x; the [64, F] hidden activation never leaves the CU:
-// F is walked in chunks of 128 columns, each chunk is produced by GEMM1 (swapped
-// orientation, so a lane owns one frame and 4 consecutive hidden features per
-// register quad), SiLU'd, written to LDS as the next A operand (ds_write_b64,
-// row-major [frame][hidden]) and consumed by GEMM2 into the [64, 256] output
-// accumulators that stay in registers for all chunks.  Weights stream from L2/HBM
-// as pre-packed 1-KiB fragments straight into registers (each wave owns distinct
-// weight rows, so there is nothing to share through LDS).
+// One 512-thread workgroup (8 waves, two per SIMD) owns 64 rows of x; the [64, F] hidden
+// activation never leaves the CU.  F is walked in chunks of 256 hidden units:
+//   GEMM1 (swapped orientation: a lane owns one frame, a register quad 4 consecutive hidden
+//          units) - wave w produces hidden units [32w, 32w+32) of the chunk for all 64 rows;
+//          accumulators start at the bias; SiLU in the exp2 domain (log2 e folded into the
+//          packed W1/b1, 1/log2 e into W2); hi/lo split; ds_write_b64 into H[frame][hidden].
+//   GEMM2 (normal orientation) - wave w accumulates output columns [32w, 32w+32) over the chunk.
+// Each wave streams its own, disjoint weight fragments from L2 straight into a register ring
+// (1 KiB per load, lane-linear); the ring of a stage is filled during the PREVIOUS stage, so no
+// stage starts with an empty pipeline.  Two waves per SIMD overlap one wave's SiLU / LDS / VMEM
+// latency with the other's MFMAs.  Two workgroup barriers per chunk (H is single-buffered: the
+// LDS holds the LN(x) planes, 66 KiB, and the H planes, 66 KiB).
 //
-// Algorithmic work: 2*2*D*F flop per row = 2.097 MFLOP (D=256, F=2048);
-// bound: MFMA.  HBM traffic per launch: x read+write 2*M*1 KiB, weights 2 MiB
-// fp16 per plane (L2-resident after the first workgroups).
+// Algorithmic work: 4*D*F flop per row (2.097 MFLOP at D=256, F=2048); bound: MFMA.
+// Executed MFMA work is NP x that.  HBM/L2 traffic per launch: x read+write 2 KiB/row; each
+// workgroup streams all 2*D*F*2 B (x2 planes when NP=3) of weights once from L2.
 #include "eec_kernels.h"
 
 namespace eec {
 
-constexpr int kFC = 128;                          // hidden columns per chunk
-constexpr int kHLd = (kFC + 8) * 2;               // 272
-constexpr int kHPlane = kTileRows * kHLd;         // 17408
-constexpr int kFfnLds = 2 * kAPlane + 4 * kHPlane;  // 137216
+constexpr int kFfnThreads = 512;
+constexpr int kFC = 256;                 // hidden units per chunk
+constexpr int kFfnLds = 4 * kAPlane;     // A hi/lo + H hi/lo planes, all [64][264] fp16 = 135168 B
+constexpr int kPF = 4;                   // k-steps of weights kept in flight per wave
 
 template <int NP, bool FINAL_LN>
-__global__ __launch_bounds__(kThreads, 1) void ffn_kernel(float* __restrict__ x, int M,
-                                                          const float* __restrict__ ln_g,
-                                                          const float* __restrict__ ln_b,
-                                                          const uint4* __restrict__ w1p,
-                                                          const float* __restrict__ b1,
-                                                          const uint4* __restrict__ w2p,
-                                                          const float* __restrict__ b2, int F,
-                                                          const float* __restrict__ fin_g,
-                                                          const float* __restrict__ fin_b) {
+__global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__ x, int M,
+                                                             const float* __restrict__ ln_g,
+                                                             const float* __restrict__ ln_b,
+                                                             const uint4* __restrict__ w1p,
+                                                             const float* __restrict__ b1s,
+                                                             const uint4* __restrict__ w2p,
+                                                             const float* __restrict__ b2, int F,
+                                                             const float* __restrict__ fin_g,
+                                                             const float* __restrict__ fin_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_a = smem;
   char* lds_h = smem + 2 * kAPlane;
   const int lane = lane_id(), w = wave_id();
+  const int hh = lane >> 5;
   const int row0 = blockIdx.x * kTileRows;
 
-  rows_f32_to_planes<NP, true>(lds_a, x, row0, M, ln_g, ln_b);
+  rows_f32_to_planes<NP, true, 8>(lds_a, x, row0, M, ln_g, ln_b);
+
+  const int nft = F / 32;                // 32-wide hidden tiles
+  const int nchunk = (nft + 7) / 8;
+  const int ks2_total = F / 16;
+  const char* a_lane = lds_a + (lane & 31) * kALd + hh * 16;
+  const char* h_lane = lds_h + (lane & 31) * kALd + hh * 16;
+
+  WRing<NP, kPF> r1, r2;
+  if (w < nft) ring_fill<NP, kPF>(r1, w1p + (size_t)w * (kD / 16) * 128 + lane, kD / 16);
   __syncthreads();
 
-  f32x16 acc2[2][2];
+  f32x16 acc2[2][1];
   zero_acc(acc2);
-  const int nchunk = F / kFC;
-  const int ks2_total = F / 16;
   for (int c = 0; c < nchunk; ++c) {
-    char* hb = lds_h + (c & 1) * 2 * kHPlane;
+    const int ft = c * 8 + w;
+    const bool active1 = ft < nft;                       // wave-uniform
+    const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
+    const uint4* w2_lane = w2p + ((size_t)w * ks2_total + c * (kFC / 16)) * 128 + lane;
+    ring_fill<NP, kPF>(r2, w2_lane, ks2);                // in flight during GEMM1
+
     f32x16 acc1[2][1];
-    zero_acc(acc1);
-    gemm_stage<NP, kD / 16, 2, 1, true>(acc1, lds_a, kALd, kAPlane, w1p, kD / 16, c * 4 + w, 0);
-    // bias + SiLU + split -> H[frame][hidden] (lane = frame, register quad = 4 consecutive hidden)
-    const int fl0 = w * 32 + 4 * (lane >> 5);
+    if (active1) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 bb = *(const float4*)(b1 + c * kFC + fl0 + 8 * g);
+      for (int g = 0; g < 4; ++g) {
+        const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          acc1[mt][0][4 * g + 0] = bb.x;
+          acc1[mt][0][4 * g + 1] = bb.y;
+          acc1[mt][0][4 * g + 2] = bb.z;
+          acc1[mt][0][4 * g + 3] = bb.w;
+        }
+      }
+      gemm_ring<NP, kD / 16, true, kPF>(acc1, a_lane, kALd, kAPlane, w1p + (size_t)ft * (kD / 16) * 128 + lane, r1);
+    }
+    __syncthreads();  // every wave has finished reading H of the previous chunk
+    if (active1) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        const int m = mt * 32 + (lane & 31);
-        h4 hi, lo;
-        EEC_SPLIT(silu_f(acc1[mt][0][4 * g + 0] + bb.x), hi, lo, 0);
-        EEC_SPLIT(silu_f(acc1[mt][0][4 * g + 1] + bb.y), hi, lo, 1);
-        EEC_SPLIT(silu_f(acc1[mt][0][4 * g + 2] + bb.z), hi, lo, 2);
-        EEC_SPLIT(silu_f(acc1[mt][0][4 * g + 3] + bb.w), hi, lo, 3);
-        *(h4*)(hb + m * kHLd + (fl0 + 8 * g) * 2) = hi;
-        if (NP == 3) *(h4*)(hb + kHPlane + m * kHLd + (fl0 + 8 * g) * 2) = lo;
+        char* dst = lds_h + (mt * 32 + (lane & 31)) * kALd + (w * 32 + 4 * hh) * 2;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const hl2_t s0 = split2<NP>(silu_exp2(acc1[mt][0][4 * g + 0]), silu_exp2(acc1[mt][0][4 * g + 1]));
+          const hl2_t s1 = split2<NP>(silu_exp2(acc1[mt][0][4 * g + 2]), silu_exp2(acc1[mt][0][4 * g + 3]));
+          h4 hi, lo;
+          hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+          *(h4*)(dst + g * 16) = hi;
+          if (NP == 3) *(h4*)(dst + kAPlane + g * 16) = lo;
+        }
       }
     }
-    __syncthreads();
-    gemm_stage<NP, kFC / 16, 2, 2, false>(acc2, hb, kHLd, kHPlane, w2p, ks2_total, 2 * w, c * (kFC / 16));
+    __syncthreads();  // H of this chunk is complete
+    if (ft + 8 < nft) ring_fill<NP, kPF>(r1, w1p + (size_t)(ft + 8) * (kD / 16) * 128 + lane, kD / 16);
+    if (ks2 == kFC / 16)
+      gemm_ring<NP, kFC / 16, false, kPF>(acc2, h_lane, kALd, kAPlane, w2_lane, r2);
+    else
+      gemm_plain<NP, false>(acc2, h_lane, kALd, kAPlane, w2_lane, ks2);
   }
-  __syncthreads();  // every wave is done with the A planes and H buffers
-  acc_to_etile<2>(smem, acc2, w * 64, b2);
+  __syncthreads();  // all waves are done with the A planes (the fp32 tile below aliases them)
+  acc_to_etile<1>(smem, acc2, w * 32, b2);
   __syncthreads();
 
   float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -82,8 +114,8 @@ __global__ __launch_bounds__(kThreads, 1) void ffn_kernel(float* __restrict__ x,
     bt = ((const float4*)fin_b)[lane];
   }
 #pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int rl = w * 16 + i, row = row0 + rl;
+  for (int i = 0; i < 8; ++i) {
+    const int rl = w * 8 + i, row = row0 + rl;
     if (row >= M) break;  // wave-uniform
     const float4 e = *(const float4*)(smem + rl * kELd + lane * 16);
     float4 v = ((const float4*)(x + (size_t)row * kD))[lane];
@@ -108,10 +140,14 @@ __global__ __launch_bounds__(kThreads, 1) void ffn_kernel(float* __restrict__ x,
 template <int NP, bool FL>
 static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {
   auto k = ffn_kernel<NP, FL>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
-  if (e != hipSuccess) return e;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
   const int grid = (a.M + kTileRows - 1) / kTileRows;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), kFfnLds, st, a.x, a.M, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), kFfnLds, st, a.x, a.M, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
                      a.b2, a.F, a.fin_g, a.fin_b);
   return hipGetLastError();
 }

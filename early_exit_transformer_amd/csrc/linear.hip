@@ -1,233 +1,311 @@
-// K=256 projection kernels of a Conformer layer, one 64-row tile per workgroup:
-//   qkv_kernel          LN -> in_proj (N=768) -> Q (pre-scaled), K, V^T in attention layouts   
+// K=256 projection kernels of a Conformer layer.  One 512-thread workgroup (8 waves) owns a
+// 64-row tile; wave w owns the 32-wide output column tile(s) {w, 8+w, 16+w}.  All products run in
+// the swapped orientation (frame on the lane, 4 consecutive output features per register quad), so
+// every epilogue stores straight from the accumulators - no LDS round trip, no barrier after the
+// prologue.  Weight fragments stream through the register ring of eec_device.h; the ring of a pass
+// is filled during the previous pass (or the prologue).  Accumulators start at the bias.
+//   qkv_kernel           LN -> in_proj (N=768) -> Q (pre-scaled), K, V^T in attention layouts   
 //   proj_residual_kernel x += A . W^T + b   (attention out_proj a6; conv pointwise-2 a7)
-//   pw1_glu_kernel      LN -> pointwise-1 (N=512) -> GLU -> fp16                                  (a7)
-//   head_kernel         exit head: Linear(D,V) -> log_softmax -> fp32 log-probs                    (a9)
-// All share: activation planes in LDS (eec_device.h), weights streamed as packed
-// fragments, results staged through an fp32 [64][256] LDS tile so that global
-// stores are whole rows.
+//   pw1_glu_kernel       LN -> pointwise-1 (N=512) -> GLU -> fp16                                  (a7)
+//   head_kernel          exit head: Linear(D,V) -> log_softmax -> fp32 log-probs                    (a9)
 #include "eec_kernels.h"
 
 namespace eec {
 
-constexpr int kLinLds = 2 * kAPlane + kETile;  // 134144
+constexpr int kLinThreads = 512;
+constexpr int kLinLds = 2 * kAPlane;  // 67584: the activation planes only
+constexpr int kLPF = 4;
 
 __device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-order of an accumulator-fed operand
   return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
 }
 
-// ---------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(kThreads, 1) void qkv_kernel(QkvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;
-  char* lds_e = smem + 2 * kAPlane;
-  const int lane = lane_id(), w = wave_id();
-  const int row0 = blockIdx.x * kTileRows;
-  const int dh = kD / a.H;
-  rows_f32_to_planes<NP, true>(lds_a, a.x, row0, a.M, a.ln_g, a.ln_b);
-  __syncthreads();
-
-  // Q (blk 0) and K (blk 1): normal orientation -> E tile -> row-wise 8-byte stores
-  for (int blk = 0; blk < 2; ++blk) {
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    gemm_stage<NP, kD / 16, 2, 2, false>(acc, lds_a, kALd, kAPlane, a.wp, kD / 16, blk * 8 + 2 * w, 0);
-    if (blk) __syncthreads();  // previous row pass finished reading the E tile
-    acc_to_etile<2>(lds_e, acc, w * 64, a.bias + blk * kD);
-    __syncthreads();
-    half_t* dst = blk == 0 ? a.q : a.k;
-    const float scale = blk == 0 ? kLog2e * rsqrtf((float)dh) : 1.0f;
-    const int col = lane * 4, hd = col / dh, d = col % dh;
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-      const int rl = w * 16 + i, row = row0 + rl;
-      if (row >= a.M) break;
-      const int b = row / a.Tq, t = row - b * a.Tq;
-      const float4 e = *(const float4*)(lds_e + rl * kELd + lane * 16);
-      h4 o;
-      o[0] = to_half_sat(e.x * scale);
-      o[1] = to_half_sat(e.y * scale);
-      o[2] = to_half_sat(e.z * scale);
-      o[3] = to_half_sat(e.w * scale);
-      *(h4*)(dst + ((size_t)(b * a.H + hd) * a.Tp + t) * dh + d) = o;
-    }
-  }
-  // V: swapped orientation (frames on lanes) -> V^T[b][h][d][perm(t)], 2-byte stores contiguous along t
-  {
-    f32x16 acc[2][2];
-    zero_acc(acc);
-    gemm_stage<NP, kD / 16, 2, 2, true>(acc, lds_a, kALd, kAPlane, a.wp, kD / 16, 16 + 2 * w, 0);
+// acc[mt][0][4g + j] <- bias[n0 + 8g + 4hh + j]  (swapped orientation: register = output feature)
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[2][1], const float* __restrict__ bias_n0) {
+  const int hh = lane_id() >> 5;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 bb = *(const float4*)(bias_n0 + 8 * g + 4 * hh);
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      const int row = row0 + mt * 32 + (lane & 31);
-      if (row < a.M) {
-        const int b = row / a.Tq, t = row - b * a.Tq;
-        const int tp = vt_perm(t);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            const int n = w * 64 + nt * 32 + acc_row(i, lane);
-            const int hd = n / dh, d = n - hd * dh;
-            a.vt[((size_t)(b * a.H + hd) * dh + d) * a.Tp + tp] =
-                to_half_sat(acc[mt][nt][i] + a.bias[2 * kD + n]);
-          }
-      }
+      acc[mt][0][4 * g + 0] = bb.x;
+      acc[mt][0][4 * g + 1] = bb.y;
+      acc[mt][0][4 * g + 2] = bb.z;
+      acc[mt][0][4 * g + 3] = bb.w;
     }
   }
 }
 
+__device__ __forceinline__ const uint4* wfrag_lane(const uint4* wp, int nt) {
+  return wp + (size_t)nt * (kD / 16) * 128 + lane_id();
+}
+
+// ---------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  const int row0 = blockIdx.x * kTileRows;
+  const int dh = kD / a.H;
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+
+  WRing<NP, kLPF> rq, rk;
+  ring_fill<NP, kLPF>(rq, wfrag_lane(a.wp, w), kD / 16);
+  rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
+  __syncthreads();
+
+  // row -> (utterance, frame) of this lane's two frames
+  int rb[2], rt[2];
+  bool ok[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = row0 + mt * 32 + (lane & 31);
+    ok[mt] = row < a.M;
+    rb[mt] = row / a.Tq;
+    rt[mt] = row - rb[mt] * a.Tq;
+  }
+  const int n0 = 32 * w, hd = n0 / dh, d0 = n0 - hd * dh + 4 * hh;
+
+  f32x16 acc[2][1];
+  // ---- Q ----
+  ring_fill<NP, kLPF>(rk, wfrag_lane(a.wp, 8 + w), kD / 16);
+  acc_init_bias(acc, a.bias + n0);
+  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), rq);
+  ring_fill<NP, kLPF>(rq, wfrag_lane(a.wp, 16 + w), kD / 16);  // V weights, in flight during the K pass
+  {
+    const float scale = kLog2e * rsqrtf((float)dh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+      if (ok[mt]) {
+        half_t* dst = a.q + ((size_t)(rb[mt] * a.H + hd) * a.Tp + rt[mt]) * dh + d0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          h4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = to_half_sat(acc[mt][0][4 * g + j] * scale);
+          *(h4*)(dst + 8 * g) = o;
+        }
+      }
+  }
+  // ---- K ----
+  acc_init_bias(acc, a.bias + kD + n0);
+  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), rk);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+    if (ok[mt]) {
+      half_t* dst = a.k + ((size_t)(rb[mt] * a.H + hd) * a.Tp + rt[mt]) * dh + d0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = to_half_sat(acc[mt][0][4 * g + j]);
+        *(h4*)(dst + 8 * g) = o;
+      }
+    }
+  // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
+  acc_init_bias(acc, a.bias + 2 * kD + n0);
+  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), rq);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+    if (ok[mt]) {
+      half_t* dst = a.vt + ((size_t)(rb[mt] * a.H + hd) * dh + d0) * a.Tp + vt_perm(rt[mt]);
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[(size_t)(8 * g + j) * a.Tp] = to_half_sat(acc[mt][0][4 * g + j]);
+    }
+}
+
+template <typename K>
+static hipError_t set_lds_once(K k, int bytes, bool& done) {
+  if (done) return hipSuccess;
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done = e == hipSuccess;
+  return e;
+}
+
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
   auto k = np == 3 ? qkv_kernel<3> : qkv_kernel<1>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kThreads), kLinLds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
+// fp16 planes in global ([M][256] hi, [M][256] lo) -> LDS planes, 512 threads.
 template <int NP>
-__global__ __launch_bounds__(kThreads, 1) void proj_residual_kernel(ProjResArgs a) {
+__device__ __forceinline__ void rows_planes_to_lds512(char* lds_act, const half_t* __restrict__ hi,
+                                                      const half_t* __restrict__ lo, int row0, int M) {
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = it * kLinThreads + t;  // 64 rows x 32 sixteen-byte pieces
+    const int rl = piece >> 5, c16 = piece & 31;
+    const int row = row0 + rl;
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+    if (row < M) {
+      vh = *(const uint4*)(hi + (size_t)row * kD + c16 * 8);
+      if (NP == 3) vl = *(const uint4*)(lo + (size_t)row * kD + c16 * 8);
+    }
+    *(uint4*)(lds_act + rl * kALd + c16 * 16) = vh;
+    if (NP == 3) *(uint4*)(lds_act + kAPlane + rl * kALd + c16 * 16) = vl;
+  }
+}
+
+template <int NP>
+__global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;
-  char* lds_e = smem + 2 * kAPlane;
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * kTileRows;
-  rows_planes_to_lds<NP>(lds_a, a.a_hi, a.a_lo, row0, a.M);
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+  WRing<NP, kLPF> r;
+  ring_fill<NP, kLPF>(r, wfrag_lane(a.wp, w), kD / 16);
+  rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
   __syncthreads();
-  f32x16 acc[2][2];
-  zero_acc(acc);
-  gemm_stage<NP, kD / 16, 2, 2, false>(acc, lds_a, kALd, kAPlane, a.wp, kD / 16, 2 * w, 0);
-  acc_to_etile<2>(lds_e, acc, w * 64, a.bias);
-  __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int rl = w * 16 + i, row = row0 + rl;
-    if (row >= a.M) break;
-    const float4 e = *(const float4*)(lds_e + rl * kELd + lane * 16);
-    float4 v = ((const float4*)(a.x + (size_t)row * kD))[lane];
-    v.x += e.x;
-    v.y += e.y;
-    v.z += e.z;
-    v.w += e.w;
-    ((float4*)(a.x + (size_t)row * kD))[lane] = v;
+  f32x16 acc[2][1];
+  acc_init_bias(acc, a.bias + 32 * w);
+  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), r);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = row0 + mt * 32 + (lane & 31);
+    if (row < a.M) {
+      float* xr = a.x + (size_t)row * kD + 32 * w + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = *(const float4*)(xr + 8 * g);
+        v.x += acc[mt][0][4 * g + 0];
+        v.y += acc[mt][0][4 * g + 1];
+        v.z += acc[mt][0][4 * g + 2];
+        v.w += acc[mt][0][4 * g + 3];
+        *(float4*)(xr + 8 * g) = v;
+      }
+    }
   }
 }
 
 hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
   auto k = np == 3 ? proj_residual_kernel<3> : proj_residual_kernel<1>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kThreads), kLinLds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(kThreads, 1) void pw1_glu_kernel(GluArgs a) {
+__global__ __launch_bounds__(kLinThreads, 2) void pw1_glu_kernel(GluArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;
-  char* lds_e = smem + 2 * kAPlane;
-  const int lane = lane_id(), w = wave_id();
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * kTileRows;
-  rows_f32_to_planes<NP, true>(lds_a, a.x, row0, a.M, a.ln_g, a.ln_b);
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+  WRing<NP, kLPF> rv, rg;
+  ring_fill<NP, kLPF>(rv, wfrag_lane(a.wp, w), kD / 16);
+  rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
   __syncthreads();
-  f32x16 av[2][2], ag[2][2];
-  zero_acc(av);
-  zero_acc(ag);
-  gemm_stage<NP, kD / 16, 2, 2, false>(av, lds_a, kALd, kAPlane, a.wp, kD / 16, 2 * w, 0);
-  gemm_stage<NP, kD / 16, 2, 2, false>(ag, lds_a, kALd, kAPlane, a.wp, kD / 16, 8 + 2 * w, 0);
+  ring_fill<NP, kLPF>(rg, wfrag_lane(a.wp, 8 + w), kD / 16);
+  f32x16 av[2][1], ag[2][1];
+  acc_init_bias(av, a.bias + 32 * w);
+  gemm_ring<NP, kD / 16, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), rv);
+  acc_init_bias(ag, a.bias + kD + 32 * w);
+  gemm_ring<NP, kD / 16, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), rg);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = w * 64 + nt * 32 + (lane & 31);
-    const float bv = a.bias[col], bg = a.bias[kD + col];
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = row0 + mt * 32 + (lane & 31);
+    if (row < a.M) {
+      half_t* dst = a.g + (size_t)row * kD + 32 * w + 4 * hh;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+      for (int g = 0; g < 4; ++g) {
+        h4 o;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = mt * 32 + acc_row(i, lane);
-        *(float*)(lds_e + r * kELd + col * 4) = (av[mt][nt][i] + bv) * sigmoid_f(ag[mt][nt][i] + bg);
+        for (int j = 0; j < 4; ++j) {
+          const float gate = ag[mt][0][4 * g + j];
+          o[j] = to_half_sat(av[mt][0][4 * g + j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * gate)));
+        }
+        *(h4*)(dst + 8 * g) = o;
       }
-  }
-  __syncthreads();
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int rl = w * 16 + i, row = row0 + rl;
-    if (row >= a.M) break;
-    const float4 e = *(const float4*)(lds_e + rl * kELd + lane * 16);
-    h4 o;
-    o[0] = to_half_sat(e.x);
-    o[1] = to_half_sat(e.y);
-    o[2] = to_half_sat(e.z);
-    o[3] = to_half_sat(e.w);
-    *(h4*)(a.g + (size_t)row * kD + lane * 4) = o;
+    }
   }
 }
 
 hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
   auto k = np == 3 ? pw1_glu_kernel<3> : pw1_glu_kernel<1>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kThreads), kLinLds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// Exit head.  V <= 256, V % 32 == 0; columns >= V are padding (-inf before the softmax).
+// Exit head.  V <= 256, V % 32 == 0.  Wave w owns vocabulary tile w (idle if 32w >= V); the
+// log-sum-exp of a frame is assembled from the 8 per-wave (max, sum) partials through LDS.
+constexpr int kHeadLds = kLinLds + 8 * 64 * 8;
+
 template <int NP>
-__global__ __launch_bounds__(kThreads, 1) void head_kernel(HeadArgs a) {
+__global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;
-  char* lds_e = smem + 2 * kAPlane;
-  const int lane = lane_id(), w = wave_id();
+  float2* stats = (float2*)(smem + kLinLds);  // [wave][frame] (max, sum exp(. - max))
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * kTileRows;
-  rows_f32_to_planes<NP, false>(lds_a, a.x, row0, a.M, nullptr, nullptr);
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+  const bool active = 32 * w < a.V;  // wave-uniform
+  WRing<NP, kLPF> r;
+  if (active) ring_fill<NP, kLPF>(r, wfrag_lane(a.wp, w), kD / 16);
+  rows_f32_to_planes<NP, false, 8>(smem, a.x, row0, a.M, nullptr, nullptr);
   __syncthreads();
-  const int ntiles = a.V / 32;
+  f32x16 acc[2][1];
+  if (active) {
+    acc_init_bias(acc, a.bias + 32 * w);
+    gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), r);
+  }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int nt = 2 * w + j;  // wave-uniform
-    if (nt < ntiles) {
-      f32x16 acc[2][1];
-      zero_acc(acc);
-      gemm_stage<NP, kD / 16, 2, 1, false>(acc, lds_a, kALd, kAPlane, a.wp, kD / 16, nt, 0);
-      const int col = nt * 32 + (lane & 31);
-      const float b = a.bias[col];
+  for (int mt = 0; mt < 2; ++mt) {
+    float mx = -INFINITY, sm = 0.f;
+    if (active) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc[mt][0][i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          *(float*)(lds_e + (mt * 32 + acc_row(i, lane)) * kELd + col * 4) = acc[mt][0][i] + b;
+      for (int i = 0; i < 16; ++i) sm += __expf(acc[mt][0][i] - mx);
+      sm += __shfl_xor(sm, 32, 64);
     }
+    if (hh == 0) stats[w * 64 + mt * 32 + lane] = make_float2(mx, sm);
   }
   __syncthreads();
-  const bool have = lane * 4 < a.V;
-#pragma unroll 4
-  for (int i = 0; i < 16; ++i) {
-    const int rl = w * 16 + i, row = row0 + rl;
-    if (row >= a.M) break;
-    float4 e = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    if (have) e = *(const float4*)(lds_e + rl * kELd + lane * 16);
-    const float mx = wave_max(fmaxf(fmaxf(e.x, e.y), fmaxf(e.z, e.w)));
-    float s = 0.f;
-    if (have) s = __expf(e.x - mx) + __expf(e.y - mx) + __expf(e.z - mx) + __expf(e.w - mx);
-    const float lse = mx + __logf(wave_sum(s));
-    if (have) {
-      e.x -= lse;
-      e.y -= lse;
-      e.z -= lse;
-      e.w -= lse;
-      *(float4*)(a.out + (size_t)row * a.V + lane * 4) = e;
+  if (!active) return;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int fr = mt * 32 + (lane & 31);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, stats[j * 64 + fr].x);
+    float sm = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float2 p = stats[j * 64 + fr];
+      sm += p.y * __expf(p.x - mx);  // inactive waves hold (-inf, 0): exp(-inf) * 0 = 0
+    }
+    const float lse = mx + __logf(sm);
+    const int row = row0 + fr;
+    if (row < a.M) {
+      float* dst = a.out + (size_t)row * a.V + 32 * w + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(dst + 8 * g) = make_float4(acc[mt][0][4 * g + 0] - lse, acc[mt][0][4 * g + 1] - lse,
+                                              acc[mt][0][4 * g + 2] - lse, acc[mt][0][4 * g + 3] - lse);
     }
   }
 }
 
 hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
   auto k = np == 3 ? head_kernel<3> : head_kernel<1>;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kLinLds);
+  hipError_t e = set_lds_once(k, kHeadLds, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kThreads), kLinLds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kHeadLds, st, a);
   return hipGetLastError();
 }
 

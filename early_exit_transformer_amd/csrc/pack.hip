@@ -5,7 +5,8 @@ namespace eec {
 
 // W[N][K] fp32 (torch Linear / 1x1-conv layout) -> MFMA fragments, hi and lo fp16 planes.
 // out[((nt*KS + s)*2 + plane)*64 + lane] = 8 halves W[32nt + (lane&31)][16s + 8(lane>>5) + j]
-__global__ void pack_frags_kernel(const float* __restrict__ w, int N, int K, uint4* __restrict__ out, int total) {
+__global__ void pack_frags_kernel(const float* __restrict__ w, int N, int K, uint4* __restrict__ out, int total,
+                                  float scale) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int lane = idx & 63, frag = idx >> 6;
@@ -15,17 +16,27 @@ __global__ void pack_frags_kernel(const float* __restrict__ w, int N, int K, uin
   h8 hi, lo;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float v = (n < N) ? w[(size_t)n * K + k0 + j] : 0.f;
+    const float v = (n < N) ? w[(size_t)n * K + k0 + j] * scale : 0.f;
     EEC_SPLIT(v, hi, lo, j);
   }
   out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
   out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
-hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, hipStream_t st) {
+hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st) {
   if (K % 16) return hipErrorInvalidValue;
   const int total = ((N + 31) / 32) * (K / 16) * 64;
-  hipLaunchKernelGGL(pack_frags_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, K, out, total);
+  hipLaunchKernelGGL(pack_frags_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, K, out, total, scale);
+  return hipGetLastError();
+}
+
+__global__ void scale_copy_kernel(const float* src, float* dst, int n, float scale) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i] * scale;
+}
+
+hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st) {
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, n, scale);
   return hipGetLastError();
 }
 

@@ -39,7 +39,7 @@ enum {
 typedef struct eec_config {
   int32_t d_model;         /* 256 in this build */
   int32_t n_heads;         /* d_model / n_heads in {32, 64} */
-  int32_t d_ff;            /* multiple of 128 */
+  int32_t d_ff;            /* multiple of 32 */
   int32_t dw_kernel;       /* odd, <= 31 */
   int32_t n_exits;         /* E */
   int32_t layers_per_exit; /* L */
