@@ -5,7 +5,8 @@ import os
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libeec.so")
+# EEC_LIB_PATH selects an alternative build of the same library (tuning experiments only)
+LIB_PATH = os.environ.get("EEC_LIB_PATH") or os.path.join(CSRC, "libeec.so")
 
 
 def build_library(jobs: int = 6, verbose: bool = False) -> str:

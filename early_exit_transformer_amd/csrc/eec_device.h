@@ -196,31 +196,51 @@ __device__ __forceinline__ void gemm_stage(f32x16 (&acc)[MT][NT], const char* ld
 // ---------------------------------------------------------------------------
 // Register ring of weight fragments: the first PF k-steps of a stage are loaded by the caller
 // one stage AHEAD (so no stage starts with an empty pipeline), the stage refills it PF ahead.
-// w_lane points at fragment (nt, s0), plane 0, this lane; consecutive k-steps are 128 uint4 apart.
+// w_lane points at fragment (nt0, s0), plane 0, this lane; consecutive k-steps are 128 uint4
+// apart, consecutive n-tiles nt_stride uint4 apart.
 // ---------------------------------------------------------------------------
-template <int NP, int PF>
+#ifdef EEC_KSTEP_STAMPS
+__device__ void eec_kstep_stamp();
+#endif
+template <int NP, int PF, int NT = 1>
 struct WRing {
-  uint4 q[PF][(NP == 3) ? 2 : 1];
+  uint4 q[PF][NT][(NP == 3) ? 2 : 1];
 };
 
-template <int NP, int PF>
-__device__ __forceinline__ void ring_fill(WRing<NP, PF>& r, const uint4* __restrict__ w_lane, int steps_avail) {
+template <int NP, int PF, int NT>
+__device__ __forceinline__ void ring_fill(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride,
+                                          int steps_avail) {
+#ifdef EEC_ABLATE_W
+  if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
+#endif
 #pragma unroll
   for (int p = 0; p < PF; ++p)
     if (p < steps_avail) {
-      r.q[p][0] = w_lane[(size_t)p * 128];
-      if (NP == 3) r.q[p][(NP == 3) ? 1 : 0] = w_lane[(size_t)p * 128 + 64];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        r.q[p][nt][0] = w_lane[nt * nt_stride + (size_t)p * 128];
+        if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = w_lane[nt * nt_stride + (size_t)p * 128 + 64];
+      }
     }
   __builtin_amdgcn_sched_barrier(0);  // keep these loads HERE: one stage ahead of their consumer
 }
 
-// acc[2][1] += Act[64 rows][16*KS] (LDS planes) x Wfrag stream; MT = 2 row tiles, one 32-wide n-tile.
+// acc[2][NT] += Act[64 rows][16*KS] (LDS planes) x Wfrag stream; MT = 2 row tiles, NT 32-wide n-tiles.
 // Software pipeline, pinned with sched_barrier(0) at every k-step boundary (hipcc otherwise sinks
 // the prefetch loads down to their first use and every step pays a full L2 round trip):
 //   step s:  ds_read A(s+1)  |  MFMAs of step s from ring slot s%PF  |  global_load W(s+PF) -> slot s%PF
-template <int NP, int KS, bool SWAP, int PF>
-__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
-                                          const uint4* __restrict__ w_lane, WRing<NP, PF>& r) {
+struct NoSide {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+// `side(s)` is called once per k-step (s is a constant after unrolling): VALU work that is issued
+// in the shadow of that step's MFMAs (e.g. the SiLU of the previous chunk).
+// SIDE_VALU > 0: after side(s), pin the order "1 MFMA, SIDE_VALU VALU" for the step, so the side
+// work's dependent VALU chain is spread over the MFMA issue gaps (an in-order wave otherwise runs it
+// as one serial chain after the MFMAs, ~150-250 exposed cycles per step).
+template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0>
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                          const uint4* __restrict__ w_lane, size_t nt_stride,
+                                          WRing<NP, PF, NT>& r, Side side = Side()) {
   constexpr int LO = (NP == 3) ? 1 : 0;
   h8 ah[2][2], al[2][2];  // [buffer][mt]
 #pragma unroll
@@ -231,56 +251,85 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][1], const char* a_lan
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int cur = s & 1, nxt = cur ^ 1;
+#ifdef EEC_ABLATE_A
+    if (s == 0) {  // timing-only build: one LDS fragment read per stage, reused for every k-step
+#else
     if (s + 1 < KS) {
+#endif
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
         if (NP == 3) al[nxt][mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + (s + 1) * 32);
       }
+      __builtin_amdgcn_sched_barrier(0);  // issue next step's LDS reads BEFORE this step's MFMAs
     }
-    const h8 bh = __builtin_bit_cast(h8, r.q[s % PF][0]);
-    const h8 bl = __builtin_bit_cast(h8, r.q[s % PF][LO]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      if (!SWAP) {
-        if (NP == 3) {
-          acc[mt][0] = mfma16(al[cur][mt], bh, acc[mt][0]);
-          acc[mt][0] = mfma16(ah[cur][mt], bl, acc[mt][0]);
+    for (int nt = 0; nt < NT; ++nt) {
+      const h8 bh = __builtin_bit_cast(h8, r.q[s % PF][nt][0]);
+      const h8 bl = __builtin_bit_cast(h8, r.q[s % PF][nt][LO]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        if (!SWAP) {
+          if (NP == 3) {
+            acc[mt][nt] = mfma16(al[cur][mt], bh, acc[mt][nt]);
+            acc[mt][nt] = mfma16(ah[cur][mt], bl, acc[mt][nt]);
+          }
+          acc[mt][nt] = mfma16(ah[cur][mt], bh, acc[mt][nt]);
+        } else {
+          if (NP == 3) {
+            acc[mt][nt] = mfma16(bh, al[cur][mt], acc[mt][nt]);
+            acc[mt][nt] = mfma16(bl, ah[cur][mt], acc[mt][nt]);
+          }
+          acc[mt][nt] = mfma16(bh, ah[cur][mt], acc[mt][nt]);
         }
-        acc[mt][0] = mfma16(ah[cur][mt], bh, acc[mt][0]);
-      } else {
-        if (NP == 3) {
-          acc[mt][0] = mfma16(bh, al[cur][mt], acc[mt][0]);
-          acc[mt][0] = mfma16(bl, ah[cur][mt], acc[mt][0]);
-        }
-        acc[mt][0] = mfma16(bh, ah[cur][mt], acc[mt][0]);
       }
     }
+#ifdef EEC_ABLATE_W
+    if (false) {  // timing-only build: no in-loop weight loads
+#else
     if (s + PF < KS) {
-      r.q[s % PF][0] = w_lane[(size_t)(s + PF) * 128];
-      if (NP == 3) r.q[s % PF][LO] = w_lane[(size_t)(s + PF) * 128 + 64];
+#endif
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        r.q[s % PF][nt][0] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128];
+        if (NP == 3) r.q[s % PF][nt][LO] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128 + 64];
+      }
+    }
+    side(s);
+    if (SIDE_VALU > 0) {
+#pragma unroll
+      for (int i = 0; i < 2 * NT * NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, SIDE_VALU, 0);  // then SIDE_VALU VALU (incl. transcendental)
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EEC_KSTEP_STAMPS
+    if (NT == 2) eec_kstep_stamp();
+#endif
   }
 }
 
 // Same product with a runtime k-step count and no ring (ragged tails only).
-template <int NP, bool SWAP>
-__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
-                                           const uint4* __restrict__ w_lane, int ks) {
+template <int NP, int NT, bool SWAP>
+__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                           const uint4* __restrict__ w_lane, size_t nt_stride, int ks) {
   for (int s = 0; s < ks; ++s) {
-    const h8 bh = __builtin_bit_cast(h8, w_lane[(size_t)s * 128]);
-    h8 bl = bh;
-    if (NP == 3) bl = __builtin_bit_cast(h8, w_lane[(size_t)s * 128 + 64]);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
-      if (NP == 3) {
-        const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
-        acc[mt][0] = SWAP ? mfma16(bh, al, acc[mt][0]) : mfma16(al, bh, acc[mt][0]);
-        acc[mt][0] = SWAP ? mfma16(bl, ah, acc[mt][0]) : mfma16(ah, bl, acc[mt][0]);
+    for (int nt = 0; nt < NT; ++nt) {
+      const h8 bh = __builtin_bit_cast(h8, w_lane[nt * nt_stride + (size_t)s * 128]);
+      h8 bl = bh;
+      if (NP == 3) bl = __builtin_bit_cast(h8, w_lane[nt * nt_stride + (size_t)s * 128 + 64]);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
+        if (NP == 3) {
+          const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
+          acc[mt][nt] = SWAP ? mfma16(bh, al, acc[mt][nt]) : mfma16(al, bh, acc[mt][nt]);
+          acc[mt][nt] = SWAP ? mfma16(bl, ah, acc[mt][nt]) : mfma16(ah, bl, acc[mt][nt]);
+        }
+        acc[mt][nt] = SWAP ? mfma16(bh, ah, acc[mt][nt]) : mfma16(ah, bh, acc[mt][nt]);
       }
-      acc[mt][0] = SWAP ? mfma16(bh, ah, acc[mt][0]) : mfma16(ah, bh, acc[mt][0]);
     }
   }
 }
@@ -300,6 +349,46 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 // Each wave handles 16 rows; a row is one coalesced 1 KiB float4 load.
 // ---------------------------------------------------------------------------
 // x fp32 [M][256] -> (optional LayerNorm) -> hi/lo planes.
+// All RPW rows of a wave are loaded first and their reductions run as RPW independent,
+// interleaved shuffle chains (a chain is 6 dependent cross-lane steps of ~100+ cycles each;
+// run one row at a time the prologue costs ~18k cycles, interleaved ~4k).
+template <int N>
+__device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float t[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], o, 64);
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += t[i];
+  }
+}
+
+// LayerNorm of N rows held as one float4 per lane per row (row = 256 columns over 64 lanes).
+template <int N>
+__device__ __forceinline__ void layer_norm_rows(float4 (&v)[N], const float4 g, const float4 bt) {
+  float s[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) s[i] = v[i].x + v[i].y + v[i].z + v[i].w;
+  wave_sum_n<N>(s);
+  float q[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float mean = s[i] * (1.0f / kD);
+    v[i].x -= mean, v[i].y -= mean, v[i].z -= mean, v[i].w -= mean;
+    q[i] = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+  }
+  wave_sum_n<N>(q);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float rs = rsqrtf(q[i] * (1.0f / kD) + kLnEps);
+    v[i].x = v[i].x * rs * g.x + bt.x;
+    v[i].y = v[i].y * rs * g.y + bt.y;
+    v[i].z = v[i].z * rs * g.z + bt.z;
+    v[i].w = v[i].w * rs * g.w + bt.w;
+  }
+}
+
 template <int NP, bool DO_LN, int RPW = 16>
 __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* __restrict__ x, int row0, int M,
                                                    const float* __restrict__ gamma,
@@ -310,27 +399,27 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
     g = ((const float4*)gamma)[lane];
     bt = ((const float4*)beta)[lane];
   }
-#pragma unroll 4
-  for (int i = 0; i < RPW; ++i) {
-    const int rl = w * RPW + i, row = row0 + rl;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < M) v = ((const float4*)(x + (size_t)row * kD))[lane];
-    if (DO_LN) {
-      const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / kD);
-      const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-      const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / kD);
-      const float rs = rsqrtf(var + kLnEps);
-      v.x = dx * rs * g.x + bt.x;
-      v.y = dy * rs * g.y + bt.y;
-      v.z = dz * rs * g.z + bt.z;
-      v.w = dw * rs * g.w + bt.w;
-      if (row >= M) v = make_float4(0.f, 0.f, 0.f, 0.f);
+  constexpr int NB = (RPW < 8) ? RPW : 8;  // rows per batch
+#pragma unroll
+  for (int b0 = 0; b0 < RPW; b0 += NB) {
+    float4 v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int row = row0 + w * RPW + b0 + i;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) v[i] = ((const float4*)(x + (size_t)row * kD))[lane];
     }
-    const hl2_t s0 = split2<NP>(v.x, v.y), s1 = split2<NP>(v.z, v.w);
-    h4 hi, lo;
-    hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
-    *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
-    if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
+    if (DO_LN) layer_norm_rows<NB>(v, g, bt);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int rl = w * RPW + b0 + i;
+      if (DO_LN && row0 + rl >= M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const hl2_t s0 = split2<NP>(v[i].x, v[i].y), s1 = split2<NP>(v[i].z, v[i].w);
+      h4 hi, lo;
+      hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+      *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
+      if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
+    }
   }
 }
 

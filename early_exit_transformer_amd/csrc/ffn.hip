@@ -3,18 +3,22 @@
 //
 //     x <- [LN_final]( 0.5 * ( W2 . silu( W1 . LN(x) + b1 ) + b2 ) + x )
 //
-// One 512-thread workgroup (8 waves, two per SIMD) owns 64 rows of x; the [64, F] hidden
-// activation never leaves the CU.  F is walked in chunks of 256 hidden units:
-//   GEMM1 (swapped orientation: a lane owns one frame, a register quad 4 consecutive hidden
-//          units) - wave w produces hidden units [32w, 32w+32) of the chunk for all 64 rows;
-//          accumulators start at the bias; SiLU in the exp2 domain (log2 e folded into the
-//          packed W1/b1, 1/log2 e into W2); hi/lo split; ds_write_b64 into H[frame][hidden].
-//   GEMM2 (normal orientation) - wave w accumulates output columns [32w, 32w+32) over the chunk.
+// One 512-thread workgroup owns 64 rows of x; the [64, F] hidden activation never leaves the CU.
+// F is walked in chunks of 128 hidden units.  The 8 waves are specialised (one wave of each kind
+// per SIMD):
+//   producers (waves 4-7): GEMM1 in the swapped orientation (lane = frame, register quad = 4
+//       consecutive hidden units; wave wl makes hidden [32wl, 32wl+32) of the chunk for all 64
+//       rows; accumulators start at the bias), SiLU in the exp2 domain (log2 e folded into W1/b1,
+//       1/log2 e into W2), hi/lo split, ds_write_b64 into H[c & 1][frame][hidden];
+//   consumers (waves 0-3): GEMM2 (normal orientation) of chunk c-1 from H[(c-1) & 1], wave wl
+//       accumulating output columns [64wl, 64wl+64) in registers that live across all chunks.
+// In slot s the producers multiply chunk s and, inside that k-loop (two values per k-step, in the
+// shadow of the step's MFMAs), SiLU chunk s-1 into H[(s-1) & 1]; the consumers eat chunk s-2.  Both
+// waves of a SIMD therefore run continuous MFMA streams of 32*NP MFMAs per slot, with ONE workgroup
+// barrier per slot.  (A stand-alone SiLU phase halves the partner wave's MFMA rate and is pure
+// critical path: measured 9.8k cycles per slot against 6.1k of MFMA work.)
 // Each wave streams its own, disjoint weight fragments from L2 straight into a register ring
-// (1 KiB per load, lane-linear); the ring of a stage is filled during the PREVIOUS stage, so no
-// stage starts with an empty pipeline.  Two waves per SIMD overlap one wave's SiLU / LDS / VMEM
-// latency with the other's MFMAs.  Two workgroup barriers per chunk (H is single-buffered: the
-// LDS holds the LN(x) planes, 66 KiB, and the H planes, 66 KiB).
+// (1 KiB per load) that runs PF k-steps ahead, across chunk boundaries.
 //
 // Algorithmic work: 4*D*F flop per row (2.097 MFLOP at D=256, F=2048); bound: MFMA.
 // Executed MFMA work is NP x that.  HBM/L2 traffic per launch: x read+write 2 KiB/row; each
@@ -24,9 +28,50 @@
 namespace eec {
 
 constexpr int kFfnThreads = 512;
-constexpr int kFC = 256;                 // hidden units per chunk
-constexpr int kFfnLds = 4 * kAPlane;     // A hi/lo + H hi/lo planes, all [64][264] fp16 = 135168 B
-constexpr int kPF = 4;                   // k-steps of weights kept in flight per wave
+constexpr int kFC = 128;                          // hidden units per chunk (4 waves x 32)
+constexpr int kHLd = (kFC + 8) * 2;               // 272
+constexpr int kHPlane = kTileRows * kHLd;         // 17408
+constexpr int kFfnLds = 2 * kAPlane + 4 * kHPlane;  // A hi/lo + per-group H hi/lo = 137216
+// k-steps of W1 / W2 fragments a producer / consumer wave keeps in flight.  The shared weight stream
+// out of L2 is latency x concurrency bound (tools/l2bw.hip: 64 KiB in flight per CU -> 18 TB/s,
+// 128 KiB -> 28 TB/s), so the rings are as deep as the register budget allows.
+#ifndef EEC_PF1_NP3
+#define EEC_PF1_NP3 8
+#define EEC_PF2_NP3 4
+#define EEC_PF1_NP1 12
+#define EEC_PF2_NP1 8
+#endif
+template <int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = EEC_PF2_NP3; };
+template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF2_NP1; };
+
+#ifdef EEC_TIMELINE
+// Diagnostic build only: s_memtime stamps of wave 0 (producer) and wave 4 (consumer) of the first
+// 8 workgroups, written to a buffer nothing else reads.  Layout: [block][role][stamp], 64 stamps.
+__device__ unsigned long long* g_timeline = nullptr;
+__device__ __forceinline__ void tl_stamp(int& idx) {
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0 && (w == 0 || w == 4) && blockIdx.x < 8 && g_timeline && idx < 64)
+    g_timeline[(blockIdx.x * 2 + (w >> 2)) * 64 + idx] = __builtin_amdgcn_s_memtime();
+  ++idx;
+}
+#define TL_STAMP() tl_stamp(tl_idx)
+#ifdef EEC_KSTEP_STAMPS
+__device__ int g_ks_idx;  // stamps of consumer wave 0, block 0 only, slots 3..5
+__device__ unsigned long long g_ks[256];
+__device__ void eec_kstep_stamp() {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && g_ks_idx < 256) g_ks[g_ks_idx++] = __builtin_amdgcn_s_memtime();
+}
+extern "C" int eec_debug_ksteps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  int zero = 0;
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ks), 256 * 8);
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ks_idx), &zero, 4);
+  return (int)e;
+}
+#endif
+#else
+#define TL_STAMP()
+#endif
 
 template <int NP, bool FINAL_LN>
 __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__ x, int M,
@@ -39,73 +84,127 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
                                                              const float* __restrict__ fin_g,
                                                              const float* __restrict__ fin_b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* lds_a = smem;
-  char* lds_h = smem + 2 * kAPlane;
+  constexpr int kPF1 = FfnPf<NP>::P1, kPF2 = FfnPf<NP>::P2;
   const int lane = lane_id(), w = wave_id();
-  const int hh = lane >> 5;
+  const int hh = lane >> 5, wl = w & 3;
+  const bool producer = w >= 4;  // wave-uniform; consumers are the OLDER waves (issue arbitration: priority, then age)
   const int row0 = blockIdx.x * kTileRows;
+  char* lds_h = smem + 2 * kAPlane;  // H[buf][plane][64][136]
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
-  rows_f32_to_planes<NP, true, 8>(lds_a, x, row0, M, ln_g, ln_b);
-
-  const int nft = F / 32;                // 32-wide hidden tiles
-  const int nchunk = (nft + 7) / 8;
+  const int nft = F / 32;  // 32-wide hidden tiles
+  const int nchunk = (nft + 3) / 4;
   const int ks2_total = F / 16;
-  const char* a_lane = lds_a + (lane & 31) * kALd + hh * 16;
-  const char* h_lane = lds_h + (lane & 31) * kALd + hh * 16;
+  const size_t w2_nt_stride = (size_t)ks2_total * 128;
 
-  WRing<NP, kPF> r1, r2;
-  if (w < nft) ring_fill<NP, kPF>(r1, w1p + (size_t)w * (kD / 16) * 128 + lane, kD / 16);
+#ifdef EEC_TIMELINE
+  int tl_idx = 0;
+#endif
+  TL_STAMP();  // 0: kernel entry
+  WRing<NP, kPF1, 1> r1;
+  WRing<NP, kPF2, 2> r2;
+  // both weight streams start before the LayerNorm prologue
+  if (producer) {
+    if (wl < nft) ring_fill<NP, kPF1, 1>(r1, w1p + (size_t)wl * (kD / 16) * 128 + lane, 0, kD / 16);
+  } else {
+    ring_fill<NP, kPF2, 2>(r2, w2p + (size_t)(2 * wl) * ks2_total * 128 + lane, w2_nt_stride, min(kFC / 16, ks2_total));
+  }
+  rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b);
+  TL_STAMP();  // 1: prologue done
   __syncthreads();
+  TL_STAMP();  // 2: after prologue barrier
 
-  f32x16 acc2[2][1];
-  zero_acc(acc2);
-  for (int c = 0; c < nchunk; ++c) {
-    const int ft = c * 8 + w;
-    const bool active1 = ft < nft;                       // wave-uniform
-    const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
-    const uint4* w2_lane = w2p + ((size_t)w * ks2_total + c * (kFC / 16)) * 128 + lane;
-    ring_fill<NP, kPF>(r2, w2_lane, ks2);                // in flight during GEMM1
-
-    f32x16 acc1[2][1];
-    if (active1) {
+  // The two roles run separate loops (so neither carries the other's registers); both execute
+  // exactly nslots workgroup barriers.  Pipeline: chunk c is multiplied (GEMM1) in slot c, SiLU'd
+  // and written to H[c & 1] in slot c+1 -- inside the k-loop of GEMM1(c+1), two values per k-step in
+  // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
+  const int nslots = nchunk + 2;
+  if (producer) {
+    // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
+    auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
+      const int mt = step >> 3, q = step & 7;
+      const hl2_t sp = split2<NP>(silu_exp2(acc[mt][0][2 * q]), silu_exp2(acc[mt][0][2 * q + 1]));
+      if ((q & 1) == 0) {
+        keep_hi = sp.hi;
+        keep_lo = sp.lo;
+      } else {
+        char* dst = hb + (mt * 32 + (lane & 31)) * kHLd + (wl * 32 + 4 * hh) * 2 + (q >> 1) * 16;
+        h4 hi, lo;
+        hi.xy = keep_hi, hi.zw = sp.hi, lo.xy = keep_lo, lo.zw = sp.lo;
+        *(h4*)dst = hi;
+        if (NP == 3) *(h4*)(dst + kHPlane) = lo;
+      }
+    };
+    auto init_bias = [&](f32x16 (&acc)[2][1], int ft) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          acc1[mt][0][4 * g + 0] = bb.x;
-          acc1[mt][0][4 * g + 1] = bb.y;
-          acc1[mt][0][4 * g + 2] = bb.z;
-          acc1[mt][0][4 * g + 3] = bb.w;
+          acc[mt][0][4 * g + 0] = bb.x;
+          acc[mt][0][4 * g + 1] = bb.y;
+          acc[mt][0][4 * g + 2] = bb.z;
+          acc[mt][0][4 * g + 3] = bb.w;
         }
       }
-      gemm_ring<NP, kD / 16, true, kPF>(acc1, a_lane, kALd, kAPlane, w1p + (size_t)ft * (kD / 16) * 128 + lane, r1);
-    }
-    __syncthreads();  // every wave has finished reading H of the previous chunk
-    if (active1) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        char* dst = lds_h + (mt * 32 + (lane & 31)) * kALd + (w * 32 + 4 * hh) * 2;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const hl2_t s0 = split2<NP>(silu_exp2(acc1[mt][0][4 * g + 0]), silu_exp2(acc1[mt][0][4 * g + 1]));
-          const hl2_t s1 = split2<NP>(silu_exp2(acc1[mt][0][4 * g + 2]), silu_exp2(acc1[mt][0][4 * g + 3]));
-          h4 hi, lo;
-          hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
-          *(h4*)(dst + g * 16) = hi;
-          if (NP == 3) *(h4*)(dst + kAPlane + g * 16) = lo;
+    };
+    // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
+    auto slot = [&](int s, f32x16 (&cur)[2][1], f32x16 (&prev)[2][1]) {
+      const int ft = s * 4 + wl;
+      const bool do_gemm = s < nchunk && ft < nft;
+      const bool do_silu = s >= 1 && s - 1 < nchunk && ft - 4 < nft;
+      char* hb_prev = lds_h + ((s - 1) & 1) * 2 * kHPlane;
+      h2 khi, klo;
+      if (do_gemm) {
+        init_bias(cur, ft);
+        const uint4* w1_lane = w1p + (size_t)ft * (kD / 16) * 128 + lane;
+        if (do_silu) {
+          auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
+          gemm_ring<NP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
+                                                                                  0, r1, side);
         }
+        else
+          gemm_ring<NP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
+        if (ft + 4 < nft)  // next chunk's W1 stream
+          ring_fill<NP, kPF1, 1>(r1, w1p + (size_t)(ft + 4) * (kD / 16) * 128 + lane, 0, kD / 16);
+      } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
+#pragma unroll
+        for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
       }
+      TL_STAMP();  // producer: slot work done
+      __syncthreads();
+      TL_STAMP();  // producer: barrier passed
+    };
+    f32x16 accA[2][1], accB[2][1];
+    for (int s = 0; s < nslots; s += 2) {
+      slot(s, accA, accB);
+      if (s + 1 < nslots) slot(s + 1, accB, accA);
     }
-    __syncthreads();  // H of this chunk is complete
-    if (ft + 8 < nft) ring_fill<NP, kPF>(r1, w1p + (size_t)(ft + 8) * (kD / 16) * 128 + lane, kD / 16);
-    if (ks2 == kFC / 16)
-      gemm_ring<NP, kFC / 16, false, kPF>(acc2, h_lane, kALd, kAPlane, w2_lane, r2);
-    else
-      gemm_plain<NP, false>(acc2, h_lane, kALd, kAPlane, w2_lane, ks2);
+  } else {
+    f32x16 acc2[2][2];
+    zero_acc(acc2);
+    for (int s = 0; s < nslots; ++s) {
+      if (s >= 2) {
+        const int c = s - 2;
+        const char* h_lane = lds_h + (c & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
+        const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
+        const uint4* w2_lane = w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
+        if (ks2 == kFC / 16)
+          gemm_ring<NP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+        else
+          gemm_plain<NP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+        if (c + 1 < nchunk)  // next chunk's W2 stream: in flight across the barrier
+          ring_fill<NP, kPF2, 2>(r2, w2_lane + (size_t)(kFC / 16) * 128, w2_nt_stride,
+                                 min(kFC / 16, ks2_total - (c + 1) * (kFC / 16)));
+      }
+      TL_STAMP();  // consumer: slot work done
+      __syncthreads();
+      TL_STAMP();  // consumer: barrier passed
+    }
+    // the consumers hold the [64, 256] result: stage it through the fp32 tile (aliases the A planes;
+    // the last barrier above guarantees no producer still reads them)
+    acc_to_etile<2>(smem, acc2, wl * 64, b2);
   }
-  __syncthreads();  // all waves are done with the A planes (the fp32 tile below aliases them)
-  acc_to_etile<1>(smem, acc2, w * 32, b2);
   __syncthreads();
 
   float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -113,29 +212,45 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     g = ((const float4*)fin_g)[lane];
     bt = ((const float4*)fin_b)[lane];
   }
-#pragma unroll 4
-  for (int i = 0; i < 8; ++i) {
-    const int rl = w * 8 + i, row = row0 + rl;
-    if (row >= M) break;  // wave-uniform
-    const float4 e = *(const float4*)(smem + rl * kELd + lane * 16);
-    float4 v = ((const float4*)(x + (size_t)row * kD))[lane];
-    v.x += 0.5f * e.x;
-    v.y += 0.5f * e.y;
-    v.z += 0.5f * e.z;
-    v.w += 0.5f * e.w;
-    if (FINAL_LN) {
-      const float mean = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / kD);
-      const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
-      const float var = wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / kD);
-      const float rs = rsqrtf(var + kLnEps);
-      v.x = dx * rs * g.x + bt.x;
-      v.y = dy * rs * g.y + bt.y;
-      v.z = dz * rs * g.z + bt.z;
-      v.w = dw * rs * g.w + bt.w;
+  {
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = w * 8 + i, row = row0 + rl;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) v[i] = ((const float4*)(x + (size_t)row * kD))[lane];
     }
-    ((float4*)(x + (size_t)row * kD))[lane] = v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float4 e = *(const float4*)(smem + (w * 8 + i) * kELd + lane * 16);
+      v[i].x += 0.5f * e.x;
+      v[i].y += 0.5f * e.y;
+      v[i].z += 0.5f * e.z;
+      v[i].w += 0.5f * e.w;
+    }
+    if (FINAL_LN) layer_norm_rows<8>(v, g, bt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + w * 8 + i;
+      if (row < M) ((float4*)(x + (size_t)row * kD))[lane] = v[i];
+    }
   }
+  TL_STAMP();  // last: epilogue done
 }
+
+#ifdef EEC_TIMELINE
+extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
+  static unsigned long long* dev = nullptr;
+  if (!dev) {
+    if (hipMalloc(&dev, 8 * 2 * 64 * 8) != hipSuccess) return 1;
+    (void)hipMemset(dev, 0, 8 * 2 * 64 * 8);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dev, sizeof(dev));
+    return 0;
+  }
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpy(host_out, dev, (size_t)n * 8, hipMemcpyDeviceToHost);
+}
+#endif
 
 template <int NP, bool FL>
 static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
   WRing<NP, kLPF> rq, rk;
-  ring_fill<NP, kLPF>(rq, wfrag_lane(a.wp, w), kD / 16);
+  ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, w), 0, kD / 16);
   rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
   __syncthreads();
 
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
 
   f32x16 acc[2][1];
   // ---- Q ----
-  ring_fill<NP, kLPF>(rk, wfrag_lane(a.wp, 8 + w), kD / 16);
+  ring_fill<NP, kLPF, 1>(rk, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
   acc_init_bias(acc, a.bias + n0);
-  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), rq);
-  ring_fill<NP, kLPF>(rq, wfrag_lane(a.wp, 16 + w), kD / 16);  // V weights, in flight during the K pass
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rq);
+  ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, 16 + w), 0, kD / 16);  // V weights, in flight during the K pass
   {
     const float scale = kLog2e * rsqrtf((float)dh);
 #pragma unroll
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   }
   // ---- K ----
   acc_init_bias(acc, a.bias + kD + n0);
-  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), rk);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rk);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     if (ok[mt]) {
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
     }
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
   acc_init_bias(acc, a.bias + 2 * kD + n0);
-  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), rq);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), 0, rq);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     if (ok[mt]) {
@@ -161,12 +161,12 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResAr
   const int row0 = blockIdx.x * kTileRows;
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   WRing<NP, kLPF> r;
-  ring_fill<NP, kLPF>(r, wfrag_lane(a.wp, w), kD / 16);
+  ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
   rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
   __syncthreads();
   f32x16 acc[2][1];
   acc_init_bias(acc, a.bias + 32 * w);
-  gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), r);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
@@ -202,15 +202,15 @@ __global__ __launch_bounds__(kLinThreads, 2) void pw1_glu_kernel(GluArgs a) {
   const int row0 = blockIdx.x * kTileRows;
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   WRing<NP, kLPF> rv, rg;
-  ring_fill<NP, kLPF>(rv, wfrag_lane(a.wp, w), kD / 16);
+  ring_fill<NP, kLPF, 1>(rv, wfrag_lane(a.wp, w), 0, kD / 16);
   rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
   __syncthreads();
-  ring_fill<NP, kLPF>(rg, wfrag_lane(a.wp, 8 + w), kD / 16);
+  ring_fill<NP, kLPF, 1>(rg, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
   f32x16 av[2][1], ag[2][1];
   acc_init_bias(av, a.bias + 32 * w);
-  gemm_ring<NP, kD / 16, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), rv);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rv);
   acc_init_bias(ag, a.bias + kD + 32 * w);
-  gemm_ring<NP, kD / 16, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), rg);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rg);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
@@ -253,13 +253,13 @@ __global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   const bool active = 32 * w < a.V;  // wave-uniform
   WRing<NP, kLPF> r;
-  if (active) ring_fill<NP, kLPF>(r, wfrag_lane(a.wp, w), kD / 16);
+  if (active) ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
   rows_f32_to_planes<NP, false, 8>(smem, a.x, row0, a.M, nullptr, nullptr);
   __syncthreads();
   f32x16 acc[2][1];
   if (active) {
     acc_init_bias(acc, a.bias + 32 * w);
-    gemm_ring<NP, kD / 16, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), r);
+    gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
   }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
