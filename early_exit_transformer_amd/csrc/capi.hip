@@ -74,7 +74,8 @@ struct eec_encoder {
   double prof_ms[KC_COUNT] = {0};
   long long prof_n[KC_COUNT] = {0};
   std::vector<PackedLayer> layers;
-  float *sub_w1t, *sub_b1, *sub_w2t, *sub_b2, *pe;
+  uint4 *sub_w1p, *sub_w2p;
+  float *sub_b1, *sub_b2, *pe;
   std::vector<uint4*> head_p;
   std::vector<float*> head_b;
 
@@ -111,9 +112,9 @@ struct eec_encoder {
       L.final_ln_w = arena.take<float>(D);
       L.final_ln_b = arena.take<float>(D);
     }
-    sub_w1t = arena.take<float>((size_t)cfg.n_mels * 3 * D);
+    sub_w1p = arena.take<uint4>(frag_u4(D, cfg.n_mels * 3));
     sub_b1 = arena.take<float>(D);
-    sub_w2t = arena.take<float>((size_t)D * 3 * D);
+    sub_w2p = arena.take<uint4>(frag_u4(D, 3 * D));
     sub_b2 = arena.take<float>(D);
     pe = arena.take<float>((size_t)cfg.max_len * D);
     head_p.assign(cfg.n_exits, nullptr);
@@ -129,8 +130,8 @@ struct eec_encoder {
 namespace {
 
 struct Workspace {
-  float *x, *mid;
-  half_t *q, *k, *vt, *p_hi, *p_lo, *g;
+  float* x;
+  half_t *mid_hi, *mid_lo, *q, *k, *vt, *p_hi, *p_lo, *g;
   int* enc_len;
   size_t bytes;
 };
@@ -142,7 +143,8 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   a.base = base;
   Workspace w;
   w.x = a.take<float>(M * D);
-  w.mid = a.take<float>((size_t)B * T1 * D);
+  w.mid_hi = a.take<half_t>((size_t)B * T1 * D);
+  w.mid_lo = a.take<half_t>((size_t)B * T1 * D);
   w.q = a.take<half_t>((size_t)B * Tp * D);
   w.k = a.take<half_t>((size_t)B * Tp * D);
   w.vt = a.take<half_t>((size_t)B * Tp * D);
@@ -163,6 +165,8 @@ int check_cfg(const eec_config& c) {
   if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1))
     return fail(EEC_ERR_UNSUPPORTED, "depthwise kernel must be odd and <= 31");
   if (c.vocab <= 0 || c.vocab > 256 || c.vocab % 32) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 32, <= 256");
+  if ((c.n_mels * 3) % 16 || c.n_mels * 3 > 384)
+    return fail(EEC_ERR_UNSUPPORTED, "n_mels*3 must be a multiple of 16 and <= 384 (n_mels in {16,32,48,64,80,96,112,128})");
   if (c.n_exits <= 0 || c.layers_per_exit <= 0 || c.n_mels <= 0 || c.max_len <= 0)
     return fail(EEC_ERR_BAD_ARG, "n_exits, layers_per_exit, n_mels, max_len must be positive");
   return 0;
@@ -249,9 +253,9 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
   }
-  EEC_HIP(launch_transpose_conv(p->sub0_w, D, c.n_mels, 3, enc->sub_w1t, st));
+  EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
   EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
-  EEC_HIP(launch_transpose_conv(p->sub1_w, D, D, 3, enc->sub_w2t, st));
+  EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
   EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
   EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
   for (int e = 0; e < c.n_exits; ++e) {
@@ -307,8 +311,8 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
   {
-    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1t, enc->sub_b1, enc->sub_w2t, enc->sub_b2, enc->pe, ws.mid, ws.x};
-    TIMED(KC_STEM, launch_subsample(a, st));
+    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
+    TIMED(KC_STEM, launch_subsample(a, 3, st));  // raw power mel: always hi/lo split (1 % of the flops)
   }
   ++step;
   if (done()) return finish_dbg();

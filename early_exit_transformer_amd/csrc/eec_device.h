@@ -334,6 +334,39 @@ __device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][NT], const char* a_l
   }
 }
 
+// Ring-pipelined product with a RUNTIME k-step count (swapped orientation, NT = 1): the loop is
+// unrolled by PF so ring slots stay statically indexed.  The ring must hold steps 0..PF-1.
+template <int NP, int PF>
+__device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
+                                                const uint4* __restrict__ w_lane, int ks, WRing<NP, PF, 1>& r) {
+  constexpr int LO = (NP == 3) ? 1 : 0;
+  for (int s0 = 0; s0 < ks; s0 += PF) {
+#pragma unroll
+    for (int p = 0; p < PF; ++p) {
+      const int s = s0 + p;
+      if (s < ks) {
+        const h8 bh = __builtin_bit_cast(h8, r.q[p][0][0]);
+        const h8 bl = __builtin_bit_cast(h8, r.q[p][0][LO]);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
+          if (NP == 3) {
+            const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
+            acc[mt][0] = mfma16(bh, al, acc[mt][0]);
+            acc[mt][0] = mfma16(bl, ah, acc[mt][0]);
+          }
+          acc[mt][0] = mfma16(bh, ah, acc[mt][0]);
+        }
+        if (s + PF < ks) {
+          r.q[p][0][0] = w_lane[(size_t)(s + PF) * 128];
+          if (NP == 3) r.q[p][0][LO] = w_lane[(size_t)(s + PF) * 128 + 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll

@@ -74,13 +74,15 @@ hipError_t launch_dwconv(const DwArgs& a, int np, hipStream_t st);
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]
   int B, n_mels, T, T1, Tq;
-  const float *w1t, *b1;  // w1t: [n_mels*3][256]
-  const float *w2t, *b2;  // w2t: [256*3][256]
+  const uint4* w1p;       // packed conv1 weight as [256][n_mels*3] (its own [ci][j] flattening)
+  const float* b1;
+  const uint4* w2p;       // packed conv2 weight as [256][3*256], k ordered (j, ci)
+  const float* b2;
   const float* pe;        // [max_len][256]
-  float* mid;             // [B][T1][256] scratch
+  half_t *mid_hi, *mid_lo;  // [B*T1][256] scratch planes (scaled by 2^-6)
   float* x;               // [B*Tq][256]
 };
-hipError_t launch_subsample(const SubsampleArgs& a, hipStream_t st);
+hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st);
 
 // weight packing (device -> device)
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // scale*W[N][K] -> fragments
@@ -88,7 +90,8 @@ hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, h
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
                           const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,
                           hipStream_t st);
-hipError_t launch_transpose_conv(const float* w, int cout, int cin, int ks, float* out, hipStream_t st);  // [co][ci][j] -> [ci*ks+j][co]
+// conv weight [co][ci][3] -> fragments of the [co][3*ci_total] matrix with k ordered (j, ci)
+hipError_t launch_pack_conv_jci(const float* w, int cout, int cin, uint4* out, hipStream_t st);
 hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_len, hipStream_t st);
 
 // greedy CTC (argmax -> unique_consecutive -> drop blank)

@@ -30,6 +30,32 @@ hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float sca
   return hipGetLastError();
 }
 
+// conv2 weight [co][ci][3] -> fragments of W'[co][k], k = j*cin + ci  (frame-major im2col order)
+__global__ void pack_conv_jci_kernel(const float* __restrict__ w, int cout, int cin, uint4* __restrict__ out, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, frag = idx >> 6;
+  const int K = 3 * cin, KS = K / 16;
+  const int nt = frag / KS, s = frag - nt * KS;
+  const int n = nt * 32 + (lane & 31), k0 = s * 16 + 8 * (lane >> 5);
+  h8 hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int k = k0 + i, j = k / cin, ci = k - j * cin;
+    const float v = (n < cout) ? w[((size_t)n * cin + ci) * 3 + j] : 0.f;
+    EEC_SPLIT(v, hi, lo, i);
+  }
+  out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
+  out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+
+hipError_t launch_pack_conv_jci(const float* w, int cout, int cin, uint4* out, hipStream_t st) {
+  if ((3 * cin) % 16) return hipErrorInvalidValue;
+  const int total = ((cout + 31) / 32) * (3 * cin / 16) * 64;
+  hipLaunchKernelGGL(pack_conv_jci_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, cout, cin, out, total);
+  return hipGetLastError();
+}
+
 __global__ void scale_copy_kernel(const float* src, float* dst, int n, float scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = src[i] * scale;

@@ -43,7 +43,7 @@ typedef struct eec_config {
   int32_t dw_kernel;       /* odd, <= 31 */
   int32_t n_exits;         /* E */
   int32_t layers_per_exit; /* L */
-  int32_t n_mels;          /* features_length */
+  int32_t n_mels;          /* features_length: 3*n_mels a multiple of 16, <= 384 (80 -> 240) */
   int32_t vocab;           /* dec_voc_size: multiple of 32, <= 256 */
   int32_t max_len;         /* rows of the positional-encoding table */
 } eec_config;

@@ -144,7 +144,7 @@ def test_ragged_shapes(B, T, lens):
 
 @pytest.mark.parametrize("over", [dict(n_head=4), dict(depthwise_kernel_size=7), dict(depthwise_kernel_size=1),
                                   dict(d_feed_forward=128), dict(dec_voc_size=32), dict(dec_voc_size=160),
-                                  dict(n_enc_exits=1, n_enc_layers=3), dict(features_length=40)])
+                                  dict(n_enc_exits=1, n_enc_layers=3), dict(features_length=48)])
 def test_config_surface(over):
     """--n_heads / --depthwise_kernel_size / --d_feed_forward / vocab / --n_enc_exits / --n_enc_layers_per_exit / --n_mels."""
     kw = base_kwargs(**{**dict(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256), **over})

@@ -42,7 +42,7 @@ def test_out_frames_matches_conv_arithmetic(lib):
     assert lib.eec_out_frames(1027) == 256
 
 
-@pytest.mark.parametrize("field,value,code", [("d_model", 128, 10002), ("n_heads", 3, 10001), ("d_ff", 100, 10002),
+@pytest.mark.parametrize("field,value,code", [("d_model", 128, 10002), ("n_heads", 3, 10001), ("d_ff", 100, 10002), ("n_mels", 40, 10002),
                                               ("dw_kernel", 32, 10002), ("dw_kernel", 33, 10002), ("vocab", 300, 10002),
                                               ("n_exits", 0, 10001)])
 def test_create_rejects_unsupported_configs_before_touching_the_gpu(lib, field, value, code):
