@@ -4,8 +4,11 @@
 Workload (BASELINE.json configs[1], SURVEY.md 8d "config 2"): the default 12-layer model
 (d_model 256, 8 heads, FFN 2048, depthwise K 31, 6 exits x 2 layers, vocab 256), batch 64 per GPU of
 synthetic log-normal mel [64, 80, 1027] (-> T' = 256), random-init weights from the portable
-generator.  One step = one ``Early_conformer.forward`` through the drop-in nn.Module: stem -> 12
-layers -> 6 CTC heads -> [6, 64, 256, 256] fp32 log-probs resident in HBM.
+generator.  One step = one ``Early_conformer.forward`` through the drop-in nn.Module (stem -> 12
+layers -> 6 CTC heads -> [6, 64, 256, 256] fp32 log-probs resident in HBM) followed by the fused
+per-exit CTC loss (one launch for all 6 x 64 lattices; reference train.py:53-65) and, for N > 1, the
+RCCL all-reduce of the 6 per-exit losses -- the only exchange of the batch-sharded path.  The same
+work runs at every N (weak scaling); ``forward_only`` reports the encoder forward alone at N = 1.
 
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
@@ -68,8 +71,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from early_exit_transformer_amd import synth
-    from early_exit_transformer_amd.model import Early_conformer
+    from early_exit_transformer_amd import parallel, synth
+    from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses
 
     B, T = args.batch, args.frames
     model = Early_conformer(device=dev, **CFG).eval()
@@ -79,22 +82,23 @@ def main():
     model.precision = args.precision
     mel = synth.synth_mel(B, CFG["features_length"], T, seed=rank).to(dev)
     lengths = torch.full((B,), T, dtype=torch.int64)  # padded positions count as work; full-length batch
+    tgt, tgt_len = synth.synth_targets(B, 42, CFG["dec_voc_size"], seed=rank)  # 40 BPE ids + BOS/EOS
+    tgt, tgt_len = tgt.to(dev), tgt_len.to(dev)
 
     def sync_all():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_steps(n):
+    def run_steps(n, with_loss=True):
         out = None
         for _ in range(n):
             with torch.no_grad():
                 out = model(mel, lengths)
-            if dist is not None:
-                # data-path exchange of the sharded path: the per-exit scalar statistic that the
-                # summed per-exit CTC loss reduces to (6 x fp32), one RCCL all-reduce per step
-                stat = out[:, :, :, 0].mean(dim=(1, 2))
-                dist.all_reduce(stat)
+                if with_loss:
+                    # summed per-exit CTC loss of this rank's shard, then the one collective of the
+                    # path: global-batch mean of the 6 per-exit losses (7 floats over RCCL/xGMI)
+                    loss = parallel.combine_exit_losses(exit_ctc_losses(out, tgt, tgt_len), B)
         return out
 
     run_steps(args.warmup)
@@ -130,6 +134,16 @@ def main():
         tot = sum(v[0] for v in prof.values())
         kernel_ms = {k: {"share": round(v[0] / tot, 4), "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "n": v[1]}
                      for k, v in prof.items()}
+
+    forward_only = None
+    if rank == 0 and world == 1:
+        run_steps(3, with_loss=False)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_steps(args.steps, with_loss=False)
+        torch.cuda.synchronize()
+        d = time.perf_counter() - t1
+        forward_only = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4)}
 
     # ---- the other operand modes (reported, never the headline) ----
     modes = {}
@@ -173,7 +187,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "mel-frames/sec encoder forward (all exits), d_model=256 12-layer",
+            "metric": "mel-frames/sec encoder forward (all exits) + summed per-exit CTC loss, d_model=256 12-layer",
             "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": {"f16x3": "fp16x3 (hi/lo-split fp16 MFMA operands, fp32 accumulate)",
@@ -184,7 +198,8 @@ def main():
                        "precision_mode": args.precision, "parity_tolerance_logp": {"f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}[args.precision]},
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
-            "roofline": roofline, "cpu_baseline": cpu, "kernel_time": kernel_ms, "modes": modes,
+            "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
+            "modes": modes,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -58,7 +58,7 @@ class EecParams(C.Structure):
 
 EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
-           "eec_encoder_set_profiling", "eec_encoder_profile_read"]
+           "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj", "glu", "dw", "head"]
 
 _lib: Optional[C.CDLL] = None
@@ -87,6 +87,8 @@ def load() -> C.CDLL:
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     lib.eec_greedy_ctc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
+    lib.eec_ctc_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     _lib = lib

@@ -363,6 +363,16 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   return finish_dbg();
 }
 
+int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                 int blank, float* nll_scratch, float* loss_per_exit, void* stream) {
+  if (!logp || !targets || !target_len || !nll_scratch || !loss_per_exit) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (E <= 0 || B <= 0 || Tq <= 0 || V <= 0 || S <= 0) return fail(EEC_ERR_BAD_ARG, "bad size");
+  if (2 * S + 1 > 512) return fail(EEC_ERR_UNSUPPORTED, "target length above 255");
+  EEC_HIP(launch_ctc_loss(logp, (const long long*)targets, (const long long*)target_len, E, B, Tq, V, S, blank, nll_scratch,
+                          loss_per_exit, (hipStream_t)stream));
+  return 0;
+}
+
 int eec_encoder_set_profiling(eec_encoder* enc, int enable, int max_launches) {
   if (!enc) return fail(EEC_ERR_BAD_ARG, "null argument");
   for (hipEvent_t e : enc->ev) (void)hipEventDestroy(e);

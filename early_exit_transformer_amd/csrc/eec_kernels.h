@@ -98,4 +98,8 @@ hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_
 hipError_t launch_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int* tokens, int* counts,
                              hipStream_t st);
 
+// batched CTC forward: per-lattice negative log-likelihoods nll[E*B] and per-exit batch-mean losses out[E]
+hipError_t launch_ctc_loss(const float* logp, const long long* targets, const long long* target_len, int E, int B, int Tq,
+                           int V, int S, int blank, float* nll, float* out, hipStream_t st);
+
 }  // namespace eec

@@ -219,6 +219,26 @@ def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
     return tokens, counts
 
 
+def exit_ctc_losses(enc_out: Tensor, targets: Tensor, target_len: Tensor, blank: int = 0) -> Tensor:
+    """Per-exit CTC losses [E] of an encoder output [E, B, T', V] in ONE launch: what train.py:53-65 computes with
+    E separate nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) calls and input length T' for every
+    utterance.  ``.sum()`` is the reference's training loss.  Forward only (no autograd)."""
+    if not enc_out.is_cuda:
+        raise RuntimeError("exit_ctc_losses runs on a HIP device only")
+    enc_out = enc_out.contiguous().float()
+    E, B, Tq, V = enc_out.shape
+    dev = enc_out.device
+    tg = targets.to(device=dev, dtype=torch.int64).contiguous()
+    tl = target_len.to(device=dev, dtype=torch.int64).contiguous()
+    nll = torch.empty((E * B,), dtype=torch.float32, device=dev)
+    out = torch.empty((E,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        capi.check(capi.load().eec_ctc_loss(enc_out.data_ptr(), tg.data_ptr(), tl.data_ptr(), E, B, Tq, V, tg.size(1), blank,
+                                            nll.data_ptr(), out.data_ptr(), C.c_void_p(stream)), "eec_ctc_loss")
+    return out
+
+
 class full_conformer(_HipEncoderMixin, nn.Module):
     """AED model: HIP encoder (this repo's scope) + the reference's PyTorch attention decoder
     (``nn.TransformerDecoder`` stays on PyTorch-ROCm)."""

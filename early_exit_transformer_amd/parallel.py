@@ -25,6 +25,8 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
 def combine_exit_losses(local_mean: torch.Tensor, b_local: int, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
     """All-reduce of per-exit batch-mean losses [E] (or a scalar) to the global-batch mean.
     One collective of E+1 floats; latency-bound over xGMI."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return local_mean  # single shard: the local batch mean already is the global one
     buf = torch.cat([local_mean.reshape(-1).to(torch.float32) * float(b_local),
                      torch.tensor([float(b_local)], dtype=torch.float32, device=local_mean.device)])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:

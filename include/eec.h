@@ -119,6 +119,14 @@ int eec_encoder_profile_read(eec_encoder* enc, double* ms_by_class, long long* l
 int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32_t* tokens, int32_t* counts,
                    void* stream);
 
+/* Replaces the per-exit loss loop of the CTC training/eval step (train.py:53-65 with
+ * nn.CTCLoss(blank, reduction='mean', zero_infinity=True), train.py:259), all exits and utterances in one launch:
+ *   logp [E, B, T', V] fp32 log-probs (the encoder output as is; input length = T' for every utterance)
+ *   targets [B, S] int64, target_len [B] int64 (device copies of the caller's tensors; len <= 255)
+ *   nll_scratch [E*B] fp32, loss_per_exit [E] fp32 = batch mean of nll / max(len, 1); train.py's loss = their sum. */
+int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                 int blank, float* nll_scratch, float* loss_per_exit, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

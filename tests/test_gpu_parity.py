@@ -12,7 +12,7 @@ import torch
 
 from conftest import base_kwargs, load_golden
 from early_exit_transformer_amd import synth
-from early_exit_transformer_amd.model import Early_conformer, full_conformer, greedy_ctc
+from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses, full_conformer, greedy_ctc
 from oracle import conformer_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -173,6 +173,25 @@ def test_full_conformer_encoder_taps_golden():
             assert np.abs(tap - z["taps"][n - 1]).max() < 1e-3
         dec, enc = fc(mel.cuda(), lens, torch.tensor([[1, 5, 9, 2]]).cuda())
     assert dec.shape == (2, 1, 4, 256) and enc.shape == (2, 1, 50, 256)
+
+
+@pytest.mark.parametrize("E,B,T,V,S", [(3, 4, 50, 32, 12), (6, 5, 256, 256, 42), (2, 3, 33, 64, 1), (1, 2, 300, 256, 150), (2, 2, 10, 32, 12)])
+def test_exit_ctc_losses_match_torch_ctc(E, B, T, V, S):
+    """Summed per-exit CTC loss (train.py:53-65) vs the oracle's nn.CTCLoss loop on the same log-probs, incl.
+    repeated labels (no skip transition), single-label targets and an infeasible utterance (zero_infinity)."""
+    torch.manual_seed(E * 100 + T)
+    logp = torch.log_softmax(torch.randn(E, B, T, V) * 2, -1)
+    tgt, tl = synth.synth_targets(B, max(S, 3), V, seed=T) if S >= 3 else (torch.full((B, 1), 5), torch.ones(B, dtype=torch.int64))
+    tgt = tgt.clone()
+    if S >= 3:
+        tgt[0, 2] = tgt[0, 1]  # a repeated label
+    # (2, 2, 10, 32, 12): 12 labels in 10 frames is infeasible -> +inf -> zeroed by zero_infinity
+    got = exit_ctc_losses(logp.cuda(), tgt, tl).cpu()
+    ctc = torch.nn.CTCLoss(blank=0, reduction="mean", zero_infinity=True)
+    il = torch.full((B,), T, dtype=torch.long)
+    want = torch.stack([ctc(logp[e].permute(1, 0, 2), tgt, il, tl) for e in range(E)])
+    assert torch.allclose(got, want, rtol=2e-5, atol=2e-5), (got, want)
+    assert abs(got.sum().item() - R.summed_exit_ctc_loss(logp, tgt, tl).item()) < 1e-4 * max(1.0, want.sum().item())
 
 
 def test_reload_weights_repacks():
