@@ -332,17 +332,22 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
         ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
-        TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
-      }
-      ++step;
-      if (done()) return finish_dbg();
-      {
         GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
-        TIMED(KC_GLU, launch_pw1_glu(ga, np_o, st));
+        // out-proj + residual and the conv module's LN -> pointwise-1 -> GLU share one launch
+        // (the sub-step hook stops between them, so it falls back to the two separate kernels)
+        const bool split_here = stop_after >= 0 && step + 1 > stop_after;
+        if (split_here) {
+          TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
+        } else {
+          TIMED(KC_PROJ, launch_proj_glu(pr, ga, np_o, st));
+        }
+        ++step;
+        if (done()) return finish_dbg();
+      }
+      {
         DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-        TIMED(KC_DW, launch_dwconv(da, np_o, st));
-        ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.conv_pw2_p, L.conv_pw2_b};
-        TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
+        ProjResArgs pr{ws.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+        TIMED(KC_DW, launch_dw_pw2(da, pr, np_o, st));
       }
       ++step;
       if (done()) return finish_dbg();

@@ -1,68 +1,150 @@
-// Convolution-side kernels of the path (all HBM/VALU-bound, fp32 arithmetic):
-//   dwconv_kernel      depthwise Conv1d(K<=31, groups=D, 'same') + BatchNorm(eval, folded) + SiLU   
-// Layout everywhere: [utterance][frame][channel], channel fastest, so lanes run over
-// channels and every global access is a contiguous row segment.
+// Conv-module tail: depthwise Conv1d(K<=31, groups=D, 'same') + BatchNorm(eval, folded) + SiLU fused into
+// the pointwise-2 GEMM + residual.  Layout everywhere: [utterance][frame][channel], channel fastest.
 #include "eec_kernels.h"
 
 namespace eec {
 
 // ---------------------------------------------------------------------------
-// Depthwise conv: thread = 2 adjacent channels x 16 output frames; the 46-frame input window
-// lives in registers.  Zero padding only at utterance ends (reference behaviour: padded
-// frames inside the batch tensor do leak into valid frames).
+// Fused conv-module tail:
+//     x += PW2( SiLU( BN( DW_K(g) ) ) ) + b      g = GLU output, fp16 [B*T'][256]
+// One 512-thread workgroup = 64 consecutive rows of the flattened (utterance, frame) axis.
+//   1. stage g rows [row0-15, row0+79) (94 x 512 B) and the folded taps [31][256] in LDS;
+//   2. depthwise conv + folded BatchNorm + SiLU: thread = 2 adjacent channels x 16 frames, window read
+//      from LDS (lanes = consecutive channels: conflict-free); zero padding at UTTERANCE ends only
+//      (reference behaviour: padded frames inside the batch tensor do leak into valid frames);
+//      result split hi/lo and written straight into the A-plane layout of the GEMM - the conv
+//      output never touches HBM;
+//   3. pointwise-2 as the ring-pipelined MFMA GEMM (wave w -> columns [32w, 32w+32)), residual add
+//      straight from the accumulators.
 // ---------------------------------------------------------------------------
 constexpr int kDwTaps = 31;
+constexpr int kDwHalo = (kDwTaps - 1) / 2;
 constexpr int kDwFrames = 16;
+constexpr int kDwWin = kDwFrames + kDwTaps - 1;            // 46
+constexpr int kGRows = kTileRows + kDwTaps - 1;             // 94 staged rows
+constexpr int kGLd = kD * 2;                                // 512 B per staged row
+constexpr int kDwLds = 2 * kAPlane + kGRows * kGLd + kDwTaps * kD * 4;  // 67584 + 48128 + 31744 = 147456
+constexpr int kDPF = 4;
 
 template <int NP>
-__global__ __launch_bounds__(kThreads) void dwconv_kernel(DwArgs a) {
-  const int c2 = threadIdx.x & 127, half = threadIdx.x >> 7;
-  const int b = blockIdx.y;
-  const int t0 = (blockIdx.x * 2 + half) * kDwFrames;
-  if (t0 >= a.Tq) return;
-  const int c = c2 * 2;
-  float2 win[kDwFrames + kDwTaps - 1];
-#pragma unroll
-  for (int j = 0; j < kDwFrames + kDwTaps - 1; ++j) {
-    const int t = t0 - (kDwTaps - 1) / 2 + j;
-    float2 v = make_float2(0.f, 0.f);
-    if (t >= 0 && t < a.Tq) {
-      const h2 g = *(const h2*)(a.g + ((size_t)b * a.Tq + t) * kD + c);
-      v = make_float2((float)g[0], (float)g[1]);
-    }
-    win[j] = v;
+__global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_g = smem + 2 * kAPlane;
+  float* lds_w = (float*)(lds_g + kGRows * kGLd);
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  const int row0 = blockIdx.x * kTileRows;
+  const int M = a.M, Tq = d.Tq;
+
+  WRing<NP, kDPF, 1> r;
+  const uint4* w_lane = a.wp + (size_t)w * (kD / 16) * 128 + lane;
+  ring_fill<NP, kDPF, 1>(r, w_lane, 0, kD / 16);
+  for (int p = threadIdx.x; p < kGRows * 32; p += 512) {
+    const int rl = p >> 5, c16 = p & 31, row = row0 - kDwHalo + rl;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row >= 0 && row < M) v = *(const uint4*)(d.g + (size_t)row * kD + c16 * 8);
+    *(uint4*)(lds_g + rl * kGLd + c16 * 16) = v;
   }
-  const float2 bias = *(const float2*)(a.bfold + c);
-  float2 acc[kDwFrames];
+  for (int p = threadIdx.x; p < kDwTaps * kD / 4; p += 512) ((float4*)lds_w)[p] = ((const float4*)d.wfold)[p];
+  __syncthreads();
+  {
+    const int c = (threadIdx.x & 127) * 2, tg = threadIdx.x >> 7;  // 2 channels x frames [16 tg, 16 tg + 16)
+    const int m0 = row0 + tg * kDwFrames;                           // first output row of this thread
+    float2 win[kDwWin];
 #pragma unroll
-  for (int i = 0; i < kDwFrames; ++i) acc[i] = bias;
+    for (int k = 0; k < kDwWin; ++k) {
+      const h2 g = *(const h2*)(lds_g + (tg * kDwFrames + k) * kGLd + c * 2);
+      win[k] = make_float2((float)g[0], (float)g[1]);
+    }
+    const float2 bias = *(const float2*)(d.bfold + c);
+    float2 acc[kDwFrames];
 #pragma unroll
-  for (int j = 0; j < kDwTaps; ++j) {
-    const float2 wv = *(const float2*)(a.wfold + j * kD + c);
+    for (int i = 0; i < kDwFrames; ++i) acc[i] = bias;
+    // window rows are flattened rows m0-15 .. m0+30; fast path when they all lie in one utterance
+    const int first = m0 - kDwHalo, last = m0 + kDwFrames - 1 + kDwHalo;
+    const bool interior = first >= 0 && last < M && first / Tq == last / Tq;  // wave-uniform (tg is per wave pair)
+    if (interior) {
+#pragma unroll
+      for (int j = 0; j < kDwTaps; ++j) {
+        const float2 wv = *(const float2*)(lds_w + j * kD + c);
+#pragma unroll
+        for (int i = 0; i < kDwFrames; ++i) {
+          acc[i].x = fmaf(wv.x, win[i + j].x, acc[i].x);
+          acc[i].y = fmaf(wv.y, win[i + j].y, acc[i].y);
+        }
+      }
+    } else {
+      // per output row i the valid window slots are [klo, khi]: same utterance as the output row
+      int klo[kDwFrames], khi[kDwFrames];
+#pragma unroll
+      for (int i = 0; i < kDwFrames; ++i) {
+        const int m = min(m0 + i, M - 1), b = m / Tq;
+        klo[i] = b * Tq - first;
+        khi[i] = (b + 1) * Tq - 1 - first;
+      }
+#pragma unroll
+      for (int j = 0; j < kDwTaps; ++j) {
+        const float2 wv = *(const float2*)(lds_w + j * kD + c);
+#pragma unroll
+        for (int i = 0; i < kDwFrames; ++i) {
+          const bool ok = (i + j) >= klo[i] && (i + j) <= khi[i];
+          acc[i].x = fmaf(ok ? wv.x : 0.f, win[i + j].x, acc[i].x);
+          acc[i].y = fmaf(ok ? wv.y : 0.f, win[i + j].y, acc[i].y);
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < kDwFrames; ++i) {
-      acc[i].x = fmaf(wv.x, win[i + j].x, acc[i].x);
-      acc[i].y = fmaf(wv.y, win[i + j].y, acc[i].y);
+      const int rl = tg * kDwFrames + i;
+      float vx = silu_f(acc[i].x), vy = silu_f(acc[i].y);
+      if (row0 + rl >= M) vx = vy = 0.f;
+      const hl2_t sp = split2<NP>(vx, vy);
+      *(h2*)(smem + rl * kALd + c * 2) = sp.hi;
+      if (NP == 3) *(h2*)(smem + kAPlane + rl * kALd + c * 2) = sp.lo;
     }
   }
+  __syncthreads();
+  f32x16 acc2[2][1];
 #pragma unroll
-  for (int i = 0; i < kDwFrames; ++i) {
-    const int t = t0 + i;
-    if (t < a.Tq) {
-      h2 hi, lo;
-      EEC_SPLIT(silu_f(acc[i].x), hi, lo, 0);
-      EEC_SPLIT(silu_f(acc[i].y), hi, lo, 1);
-      const size_t off = ((size_t)b * a.Tq + t) * kD + c;
-      *(h2*)(a.o_hi + off) = hi;
-      if (NP == 3) *(h2*)(a.o_lo + off) = lo;
+  for (int g = 0; g < 4; ++g) {
+    const float4 bb = *(const float4*)(a.bias + 32 * w + 8 * g + 4 * hh);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      acc2[mt][0][4 * g + 0] = bb.x;
+      acc2[mt][0][4 * g + 1] = bb.y;
+      acc2[mt][0][4 * g + 2] = bb.z;
+      acc2[mt][0][4 * g + 3] = bb.w;
+    }
+  }
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+  gemm_ring<NP, kD / 16, 1, true, kDPF>(acc2, a_lane, kALd, kAPlane, w_lane, 0, r);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = row0 + mt * 32 + (lane & 31);
+    if (row < M) {
+      float* xr = a.x + (size_t)row * kD + 32 * w + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = *(const float4*)(xr + 8 * g);
+        v.x += acc2[mt][0][4 * g + 0];
+        v.y += acc2[mt][0][4 * g + 1];
+        v.z += acc2[mt][0][4 * g + 2];
+        v.w += acc2[mt][0][4 * g + 3];
+        *(float4*)(xr + 8 * g) = v;
+      }
     }
   }
 }
 
-hipError_t launch_dwconv(const DwArgs& a, int np, hipStream_t st) {
-  auto k = np == 3 ? dwconv_kernel<3> : dwconv_kernel<1>;
-  const int tiles = (a.Tq + 2 * kDwFrames - 1) / (2 * kDwFrames);
-  hipLaunchKernelGGL(k, dim3(tiles, a.B), dim3(kThreads), 0, st, a);
+hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
+  auto k = np == 3 ? dw_pw2_kernel<3> : dw_pw2_kernel<1>;
+  bool& done = np == 3 ? d3 : d1;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLds);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(512), kDwLds, st, d, a);
   return hipGetLastError();
 }
 

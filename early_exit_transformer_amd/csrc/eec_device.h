@@ -113,7 +113,7 @@ __device__ __forceinline__ float silu_exp2(float u) {
   return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u));
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
@@ -237,14 +237,14 @@ struct NoSide {
 // SIDE_VALU > 0: after side(s), pin the order "1 MFMA, SIDE_VALU VALU" for the step, so the side
 // work's dependent VALU chain is spread over the MFMA issue gaps (an in-order wave otherwise runs it
 // as one serial chain after the MFMAs, ~150-250 exposed cycles per step).
-template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0>
-__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int MT = 2>
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
                                           const uint4* __restrict__ w_lane, size_t nt_stride,
                                           WRing<NP, PF, NT>& r, Side side = Side()) {
   constexpr int LO = (NP == 3) ? 1 : 0;
-  h8 ah[2][2], al[2][2];  // [buffer][mt]
+  h8 ah[2][MT], al[2][MT];  // [buffer][mt]
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
     if (NP == 3) al[0][mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes);
   }
@@ -257,7 +257,7 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][NT], const char* a_la
     if (s + 1 < KS) {
 #endif
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
         if (NP == 3) al[nxt][mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + (s + 1) * 32);
       }
@@ -268,7 +268,7 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][NT], const char* a_la
       const h8 bh = __builtin_bit_cast(h8, r.q[s % PF][nt][0]);
       const h8 bl = __builtin_bit_cast(h8, r.q[s % PF][nt][LO]);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         if (!SWAP) {
           if (NP == 3) {
             acc[mt][nt] = mfma16(al[cur][mt], bh, acc[mt][nt]);
@@ -298,7 +298,7 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[2][NT], const char* a_la
     side(s);
     if (SIDE_VALU > 0) {
 #pragma unroll
-      for (int i = 0; i < 2 * NT * NP; ++i) {
+      for (int i = 0; i < MT * NT * NP; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
         __builtin_amdgcn_sched_group_barrier(0x002, SIDE_VALU, 0);  // then SIDE_VALU VALU (incl. transcendental)
       }

@@ -44,6 +44,8 @@ struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,256), gate cols [25
   half_t* g;  // [M][256] fp16
 };
 hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st);
+// fused: attention out-proj + residual -> conv LayerNorm -> pointwise-1 -> GLU (g.x is ignored: rows come from a.x)
+hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st);
 
 struct HeadArgs {  // out = log_softmax(x . W^T + b)
   const float* x;
@@ -69,7 +71,8 @@ struct DwArgs {
   const float* bfold;  // [256]
   half_t *o_hi, *o_lo;
 };
-hipError_t launch_dwconv(const DwArgs& a, int np, hipStream_t st);
+// fused depthwise conv + BN + SiLU -> pointwise-2 + residual (o_hi/o_lo of DwArgs are unused)
+hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st);
 
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]

@@ -21,13 +21,14 @@ __device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-or
 }
 
 // acc[mt][0][4g + j] <- bias[n0 + 8g + 4hh + j]  (swapped orientation: register = output feature)
-__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[2][1], const float* __restrict__ bias_n0) {
+template <int MT>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MT][1], const float* __restrict__ bias_n0) {
   const int hh = lane_id() >> 5;
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     const float4 bb = *(const float4*)(bias_n0 + 8 * g + 4 * hh);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
       acc[mt][0][4 * g + 0] = bb.x;
       acc[mt][0][4 * g + 1] = bb.y;
       acc[mt][0][4 * g + 2] = bb.z;
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   f32x16 acc[2][1];
   // ---- Q ----
   ring_fill<NP, kLPF, 1>(rk, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
-  acc_init_bias(acc, a.bias + n0);
+  acc_init_bias<2>(acc, a.bias + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rq);
   ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, 16 + w), 0, kD / 16);  // V weights, in flight during the K pass
   {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
       }
   }
   // ---- K ----
-  acc_init_bias(acc, a.bias + kD + n0);
+  acc_init_bias<2>(acc, a.bias + kD + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rk);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
       }
     }
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
-  acc_init_bias(acc, a.bias + 2 * kD + n0);
+  acc_init_bias<2>(acc, a.bias + 2 * kD + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), 0, rq);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
@@ -154,21 +155,34 @@ __device__ __forceinline__ void rows_planes_to_lds512(char* lds_act, const half_
   }
 }
 
-template <int NP>
+// MT = 32-row tiles per workgroup: MT = 1 halves the tile (512 workgroups, two per CU, 16 waves per
+// CU): these K=256 kernels are latency-bound, so the extra occupancy pays for streaming the (small)
+// weight matrix twice as often.
+template <int NP, int MT>
 __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = 32 * MT, PLANE = ROWS * kALd;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
-  const int row0 = blockIdx.x * kTileRows;
+  const int row0 = blockIdx.x * ROWS;
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
-  WRing<NP, kLPF> r;
+  WRing<NP, kLPF, 1> r;
   ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
-  rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
+  for (int piece = threadIdx.x; piece < ROWS * 32; piece += kLinThreads) {
+    const int rl = piece >> 5, c16 = piece & 31, row = row0 + rl;
+    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+    if (row < a.M) {
+      vh = *(const uint4*)(a.a_hi + (size_t)row * kD + c16 * 8);
+      if (NP == 3) vl = *(const uint4*)(a.a_lo + (size_t)row * kD + c16 * 8);
+    }
+    *(uint4*)(smem + rl * kALd + c16 * 16) = vh;
+    if (NP == 3) *(uint4*)(smem + PLANE + rl * kALd + c16 * 16) = vl;
+  }
   __syncthreads();
-  f32x16 acc[2][1];
-  acc_init_bias(acc, a.bias + 32 * w);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
+  f32x16 acc[MT][1];
+  acc_init_bias<MT>(acc, a.bias + 32 * w);
+  gemm_ring<NP, kD / 16, 1, true, kLPF, NoSide, 0, MT>(acc, a_lane, kALd, PLANE, wfrag_lane(a.wp, w), 0, r);
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
     if (row < a.M) {
       float* xr = a.x + (size_t)row * kD + 32 * w + 4 * hh;
@@ -185,12 +199,16 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResAr
   }
 }
 
+#ifndef EEC_PROJ_MT
+#define EEC_PROJ_MT 1
+#endif
 hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st) {
   static bool d3 = false, d1 = false;
-  auto k = np == 3 ? proj_residual_kernel<3> : proj_residual_kernel<1>;
-  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
+  constexpr int MT = EEC_PROJ_MT, ROWS = 32 * MT, LDS = 2 * ROWS * kALd;
+  auto k = np == 3 ? proj_residual_kernel<3, MT> : proj_residual_kernel<1, MT>;
+  hipError_t e = set_lds_once(k, LDS, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.M + ROWS - 1) / ROWS), dim3(kLinThreads), LDS, st, a);
   return hipGetLastError();
 }
 
@@ -207,9 +225,9 @@ __global__ __launch_bounds__(kLinThreads, 2) void pw1_glu_kernel(GluArgs a) {
   __syncthreads();
   ring_fill<NP, kLPF, 1>(rg, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
   f32x16 av[2][1], ag[2][1];
-  acc_init_bias(av, a.bias + 32 * w);
+  acc_init_bias<2>(av, a.bias + 32 * w);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rv);
-  acc_init_bias(ag, a.bias + kD + 32 * w);
+  acc_init_bias<2>(ag, a.bias + kD + 32 * w);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rg);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -240,6 +258,97 @@ hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------
+// Fused attention tail + conv-module head (one launch instead of two):
+//   x += O . Wo^T + bo ;  g = GLU( LN_conv(x) . Wpw1^T + bpw1 )
+// The out-proj result crosses from "wave owns 32 columns" to "wave owns 8 rows" through an fp32
+// tile in LDS; the updated rows are LayerNorm'ed while still in registers and become the planes of
+// the GLU product.  The GLU weight stream starts before the tile exchange.
+constexpr int kProjGluLds = 2 * kAPlane + kETile;  // 134144
+
+template <int NP>
+__global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a, GluArgs gl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_e = smem + 2 * kAPlane;
+  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  const int row0 = blockIdx.x * kTileRows;
+  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
+  WRing<NP, kLPF, 1> r, rv;
+  ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
+  rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
+  __syncthreads();
+  f32x16 acc[2][1];
+  acc_init_bias<2>(acc, a.bias + 32 * w);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
+  ring_fill<NP, kLPF, 1>(rv, wfrag_lane(gl.wp, w), 0, kD / 16);  // GLU value weights: in flight during the exchange
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    char* dst = lds_e + (mt * 32 + (lane & 31)) * kELd + (32 * w + 4 * hh) * 4;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      *(float4*)(dst + g * 32) = make_float4(acc[mt][0][4 * g], acc[mt][0][4 * g + 1], acc[mt][0][4 * g + 2], acc[mt][0][4 * g + 3]);
+  }
+  __syncthreads();  // tile complete; every wave is done reading the O planes
+  {
+    const float4 g = ((const float4*)gl.ln_g)[lane], bt = ((const float4*)gl.ln_b)[lane];
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = w * 8 + i, row = row0 + rl;
+      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < a.M) v[i] = ((const float4*)(a.x + (size_t)row * kD))[lane];
+      const float4 e = *(const float4*)(lds_e + rl * kELd + lane * 16);
+      v[i].x += e.x, v[i].y += e.y, v[i].z += e.z, v[i].w += e.w;
+      if (row < a.M) ((float4*)(a.x + (size_t)row * kD))[lane] = v[i];
+    }
+    layer_norm_rows<8>(v, g, bt);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = w * 8 + i;
+      if (row0 + rl >= a.M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      const hl2_t s0 = split2<NP>(v[i].x, v[i].y), s1 = split2<NP>(v[i].z, v[i].w);
+      h4 hi, lo;
+      hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+      *(h4*)(smem + rl * kALd + lane * 8) = hi;
+      if (NP == 3) *(h4*)(smem + kAPlane + rl * kALd + lane * 8) = lo;
+    }
+  }
+  __syncthreads();
+  WRing<NP, kLPF, 1> rg;
+  ring_fill<NP, kLPF, 1>(rg, wfrag_lane(gl.wp, 8 + w), 0, kD / 16);
+  f32x16 av[2][1], ag[2][1];
+  acc_init_bias<2>(av, gl.bias + 32 * w);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(gl.wp, w), 0, rv);
+  acc_init_bias<2>(ag, gl.bias + kD + 32 * w);
+  gemm_ring<NP, kD / 16, 1, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(gl.wp, 8 + w), 0, rg);
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int row = row0 + mt * 32 + (lane & 31);
+    if (row < a.M) {
+      half_t* dst = gl.g + (size_t)row * kD + 32 * w + 4 * hh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gate = ag[mt][0][4 * g + j];
+          o[j] = to_half_sat(av[mt][0][4 * g + j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * gate)));
+        }
+        *(h4*)(dst + 8 * g) = o;
+      }
+    }
+  }
+}
+
+hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
+  static bool d3 = false, d1 = false;
+  auto k = np == 3 ? proj_glu_kernel<3> : proj_glu_kernel<1>;
+  hipError_t e = set_lds_once(k, kProjGluLds, np == 3 ? d3 : d1);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kProjGluLds, st, a, g);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Exit head.  V <= 256, V % 32 == 0.  Wave w owns vocabulary tile w (idle if 32w >= V); the
 // log-sum-exp of a frame is assembled from the 8 per-wave (max, sum) partials through LDS.
 constexpr int kHeadLds = kLinLds + 8 * 64 * 8;
@@ -258,7 +367,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
   __syncthreads();
   f32x16 acc[2][1];
   if (active) {
-    acc_init_bias(acc, a.bias + 32 * w);
+    acc_init_bias<2>(acc, a.bias + 32 * w);
     gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
   }
 #pragma unroll
