@@ -2,27 +2,28 @@
 //   loss_e = mean_b( CTC(logp[e, b], targets[b, :len_b]) / max(len_b, 1) ),  blank = 0,
 //   input length = T' for every utterance, zero_infinity=True;  train.py sums loss_e over exits.
 // All E*B lattices run in ONE launch: one wave per lattice, the extended label sequence
-// (2*len+1 states, <= 8 per lane) lives in registers, the time recursion
-//   alpha_t[s] = logsumexp(alpha_{t-1}[s], alpha_{t-1}[s-1], [alpha_{t-1}[s-2]]) + logp[t][l'_s]
-// takes its s-1 / s-2 neighbours from the previous lane with two shuffles per step, and the
-// emission row of step t+1 is gathered while step t is computed.  fp32 log space (as torch).
+// (2*len+1 states, <= 8 per lane) lives in registers.  The time recursion is latency-bound (T' serial
+// steps), so it runs in a BLOCK-FLOATING linear domain instead of log space:
+//   a_t[s] = ( a_{t-1}[s] + a_{t-1}[s-1] + [a_{t-1}[s-2]] ) * p_t(l'_s),   p = exp(logp)
+// Each lane keeps its states as fp32 mantissas times a lane-private power of two 2^e (renormalised
+// every 2 steps from the lane's own maximum: exact, no log); the two states taken from the previous
+// lane arrive with that lane's exponent and both sides are brought to the larger one.  Dynamic range
+// ACROSS lanes is therefore unbounded -- necessary, because dead-end prefixes (e.g. "all blank so
+// far") can be 1e60 times more probable than the states that will reach the end -- while the
+// dependent chain per step is 3 DPP lane shifts, a few ldexp, 2 adds and 1 multiply.  The exp of the
+// emissions is computed kCtcAhead steps earlier, off the chain.
+#include <limits.h>
+
 #include "eec_kernels.h"
 
 namespace eec {
 
 constexpr int kCtcPerLane = 8;  // up to 512 states = target length <= 255
-constexpr float kNegInf = -INFINITY;
+constexpr int kCtcEmpty = -(1 << 20);  // exponent of a lane that holds no probability mass yet
 
-__device__ __forceinline__ float lse2(float a, float b) {
-  const float m = fmaxf(a, b);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m));
-}
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-  const float m = fmaxf(fmaxf(a, b), c);
-  if (m == kNegInf) return kNegInf;
-  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
-}
+#define EEC_DPP_F(old, src, ctrl) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old)), __builtin_bit_cast(int, (float)(src)), ctrl, 0xf, 0xf, false))
+#define EEC_DPP_I(old, src, ctrl) __builtin_amdgcn_update_dpp((int)(old), (int)(src), ctrl, 0xf, 0xf, false)
 
 template <int P>
 __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__ logp, const long long* __restrict__ targets,
@@ -33,12 +34,13 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
   const int len = (int)target_len[b];
   const int L = 2 * len + 1;
   int label[P];
-  bool skip_ok[P];
+  bool skip_ok[P], live[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int s = lane * P + i;
     label[i] = blank;
     skip_ok[i] = false;
+    live[i] = s < L;
     if (s < L && (s & 1)) {
       const int k = s >> 1;
       label[i] = (int)targets[(size_t)b * S + k];
@@ -46,55 +48,75 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
     }
   }
   float alpha[P];
+  int ex = kCtcEmpty;  // this lane's states are alpha[i] * 2^ex
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int s = lane * P + i;
-    alpha[i] = (s < 2 && s < L) ? lp[label[i]] : kNegInf;
+    alpha[i] = (s < 2 && s < L) ? __expf(lp[label[i]]) : 0.f;
   }
-  // emissions are gathered kCtcAhead time steps ahead of their use (each gather is an L2 round trip)
+  if (lane == 0) ex = 0;
+  // emission probabilities are gathered (and exponentiated) kCtcAhead steps ahead of their use
   constexpr int kCtcAhead = 8;
   float emit[kCtcAhead][P];
 #pragma unroll
   for (int d = 0; d < kCtcAhead; ++d)
 #pragma unroll
-    for (int i = 0; i < P; ++i) emit[d][i] = (1 + d < Tq) ? lp[(size_t)(1 + d) * V + label[i]] : 0.f;
+    for (int i = 0; i < P; ++i) emit[d][i] = (1 + d < Tq) ? __expf(lp[(size_t)(1 + d) * V + label[i]]) : 0.f;
   for (int t0 = 1; t0 < Tq; t0 += kCtcAhead) {
 #pragma unroll
     for (int d = 0; d < kCtcAhead; ++d) {
       const int t = t0 + d;
       if (t < Tq) {  // wave-uniform
-        // neighbours from the previous lane: its last two states
-        float up1 = __shfl_up(alpha[P - 1], 1, 64), up2 = __shfl_up(alpha[P - 2], 1, 64);
-        if (lane == 0) up1 = up2 = kNegInf;
-        float nxt[P];
+        // the previous lane's last two states and its exponent (lane 0 receives 0 / its own exponent)
+        float up1 = EEC_DPP_F(0.f, alpha[P - 1], 0x138);  // wave_shr:1
+        float up2 = EEC_DPP_F(0.f, alpha[P - 2], 0x138);
+        const int ex_up = EEC_DPP_I(ex, ex, 0x138);
+        const int ec = max(ex, ex_up);  // common scale of this step
+        const int d_own = max(ex - ec, -200), d_up = max(ex_up - ec, -200);
+        up1 = ldexpf(up1, d_up);
+        up2 = ldexpf(up2, d_up);
+        float cur[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) cur[i] = ldexpf(alpha[i], d_own);
+        ex = ec;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-          // state s-1 / s-2: in this lane, or the previous lane's last (up1) / second to last (up2)
-          const float p1 = i >= 1 ? alpha[i - 1] : up1;
-          const float p2 = i >= 2 ? alpha[i - 2] : (i == 1 ? up1 : up2);
-          nxt[i] = (skip_ok[i] ? lse3(alpha[i], p1, p2) : lse2(alpha[i], p1)) + emit[d][i];
+          const float p1 = i >= 1 ? cur[i - 1] : up1;
+          const float p2 = i >= 2 ? cur[i - 2] : (i == 1 ? up1 : up2);
+          alpha[i] = live[i] ? (cur[i] + p1 + (skip_ok[i] ? p2 : 0.f)) * emit[d][i] : 0.f;
         }
+        if (d & 1) {  // renormalise this lane every second step
+          float m = alpha[0];
 #pragma unroll
-        for (int i = 0; i < P; ++i) alpha[i] = (lane * P + i < L) ? nxt[i] : kNegInf;
+          for (int i = 1; i < P; ++i) m = fmaxf(m, alpha[i]);
+          if (m > 0.f) {
+            const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
+#pragma unroll
+            for (int i = 0; i < P; ++i) alpha[i] = ldexpf(alpha[i], -e);
+            ex += e;
+          } else {
+            ex = kCtcEmpty;
+          }
+        }
         const int tn = t + kCtcAhead;
         if (tn < Tq) {
 #pragma unroll
-          for (int i = 0; i < P; ++i) emit[d][i] = lp[(size_t)tn * V + label[i]];
+          for (int i = 0; i < P; ++i) emit[d][i] = __expf(lp[(size_t)tn * V + label[i]]);
         }
       }
     }
   }
-  // -log( alpha[L-1] + alpha[L-2] )
-  float last = kNegInf, prev = kNegInf;
+  // p(target) = a[L-1] + a[L-2]: at most two lanes contribute, each with its own exponent
+  float tail = 0.f;
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int s = lane * P + i;
-    if (s == L - 1) last = alpha[i];
-    if (s == L - 2) prev = alpha[i];
+    if (s == L - 1 || s == L - 2) tail += alpha[i];
   }
-  last = wave_max(last);
-  prev = wave_max(prev);
-  if (lane == 0) nll[lat] = -lse2(last, prev);
+  const int e_lane = tail > 0.f ? ex : kCtcEmpty;
+  const int e_max = (int)wave_max((float)e_lane);  // exponents are small integers: exact in fp32
+  const float total = wave_sum(tail > 0.f ? ldexpf(tail, max(e_lane - e_max, -200)) : 0.f);
+  if (lane == 0) nll[lat] = (total > 0.f) ? -(logf(total) + (float)e_max * 0.6931471805599453f) : INFINITY;
 }
 
 // loss_e = mean_b( zero_inf(nll[e][b]) / max(len_b, 1) ): fixed summation order (bitwise reproducible)
