@@ -9,6 +9,7 @@ from typing import Optional
 from .build import LIB_PATH
 
 PREC_F16X3, PREC_MIXED, PREC_F16 = 0, 1, 2
+ARCH_CONFORMER, ARCH_LEGACY = 0, 1
 PRECISIONS = {"f16x3": PREC_F16X3, "mixed": PREC_MIXED, "f16": PREC_F16}
 
 _LAYER_FIELDS = [
@@ -43,7 +44,7 @@ LAYER_KEYS = {
 
 class EecConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("d_model", "n_heads", "d_ff", "dw_kernel", "n_exits",
-                                         "layers_per_exit", "n_mels", "vocab", "max_len")]
+                                         "layers_per_exit", "n_mels", "vocab", "max_len", "arch")]
 
 
 class EecLayerParams(C.Structure):
@@ -58,7 +59,7 @@ class EecParams(C.Structure):
 
 EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
-           "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss"]
+           "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj", "glu", "dw", "head"]
 
 _lib: Optional[C.CDLL] = None
@@ -81,6 +82,7 @@ def load() -> C.CDLL:
     lib.eec_encoder_destroy.argtypes = [C.c_void_p]
     lib.eec_encoder_destroy.restype = None
     lib.eec_encoder_pack.argtypes = [C.c_void_p, C.POINTER(EecParams), C.c_void_p]
+    lib.eec_encoder_pack_legacy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_encoder_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_workspace_bytes.restype = C.c_size_t
     lib.eec_encoder_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,

@@ -157,12 +157,13 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
 }
 
 int check_cfg(const eec_config& c) {
+  if (c.arch != EEC_ARCH_CONFORMER && c.arch != EEC_ARCH_LEGACY) return fail(EEC_ERR_BAD_ARG, "unknown arch");
   if (c.d_model != kD) return fail(EEC_ERR_UNSUPPORTED, "d_model must be 256 in this build");
   if (c.n_heads <= 0 || kD % c.n_heads) return fail(EEC_ERR_BAD_ARG, "n_heads must divide d_model");
   const int dh = kD / c.n_heads;
   if (dh != 32 && dh != 64) return fail(EEC_ERR_UNSUPPORTED, "head dim must be 32 or 64");
   if (c.d_ff <= 0 || c.d_ff % 32) return fail(EEC_ERR_UNSUPPORTED, "d_ff must be a positive multiple of 32");
-  if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1))
+  if (c.arch == EEC_ARCH_CONFORMER && (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1)))
     return fail(EEC_ERR_UNSUPPORTED, "depthwise kernel must be odd and <= 31");
   if (c.vocab <= 0 || c.vocab > 256 || c.vocab % 32) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 32, <= 256");
   if ((c.n_mels * 3) % 16 || c.n_mels * 3 > 384)
@@ -215,6 +216,7 @@ void eec_encoder_destroy(eec_encoder* enc) {
 
 int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
   if (!enc || !p || !p->layers || !p->head_w || !p->head_b) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (enc->cfg.arch != EEC_ARCH_CONFORMER) return fail(EEC_ERR_BAD_ARG, "use eec_encoder_pack_legacy for EEC_ARCH_LEGACY");
   hipStream_t st = (hipStream_t)stream;
   const eec_config& c = enc->cfg;
   const int D = c.d_model, F = c.d_ff;
@@ -252,6 +254,54 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(launch_pack_frags(s.ffn2_w2, D, F, L.ffn2_w2p, 1.0f / kLog2e, st));
     EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
+  }
+  EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
+  EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+  EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
+  EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
+  EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
+  for (int e = 0; e < c.n_exits; ++e) {
+    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
+    EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+  }
+  enc->packed = true;
+  return 0;
+}
+
+int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* stream) {
+  if (!enc || !p || !p->layers || !p->group_ln_w || !p->group_ln_b || !p->head_w || !p->head_b)
+    return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (enc->cfg.arch != EEC_ARCH_LEGACY) return fail(EEC_ERR_BAD_ARG, "encoder was not created with EEC_ARCH_LEGACY");
+  hipStream_t st = (hipStream_t)stream;
+  const eec_config& c = enc->cfg;
+  const int D = c.d_model, F = c.d_ff;
+  auto cp = [&](float* dst, const float* src, size_t n) {
+    return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
+  };
+  const size_t tile8 = (size_t)8 * (D / 16) * 128;  // 8 n-tiles (256 output columns) of a K=256 fragment matrix
+  for (size_t i = 0; i < enc->layers.size(); ++i) {
+    const eec_legacy_layer_params& s = p->layers[i];
+    PackedLayer& L = enc->layers[i];
+    const int e = (int)i / c.layers_per_exit;
+    EEC_HIP(cp(L.attn_ln_w, s.norm1_w, D));
+    EEC_HIP(cp(L.attn_ln_b, s.norm1_b, D));
+    // w_q / w_k / w_v become one [768][256] in_proj
+    EEC_HIP(launch_pack_frags(s.wq, D, D, L.attn_in_p, 1.0f, st));
+    EEC_HIP(launch_pack_frags(s.wk, D, D, L.attn_in_p + tile8, 1.0f, st));
+    EEC_HIP(launch_pack_frags(s.wv, D, D, L.attn_in_p + 2 * tile8, 1.0f, st));
+    EEC_HIP(cp(L.attn_in_b, s.bq, D));
+    EEC_HIP(cp(L.attn_in_b + D, s.bk, D));
+    EEC_HIP(cp(L.attn_in_b + 2 * D, s.bv, D));
+    EEC_HIP(launch_pack_frags(s.wo, D, D, L.attn_out_p, 1.0f, st));
+    EEC_HIP(cp(L.attn_out_b, s.bo, D));
+    EEC_HIP(cp(L.ffn2_ln_w, s.norm2_w, D));
+    EEC_HIP(cp(L.ffn2_ln_b, s.norm2_b, D));
+    EEC_HIP(launch_pack_frags(s.w1, F, D, L.ffn2_w1p, 1.0f, st));
+    EEC_HIP(cp(L.ffn2_b1, s.b1, F));
+    EEC_HIP(launch_pack_frags(s.w2, D, F, L.ffn2_w2p, 1.0f, st));
+    EEC_HIP(cp(L.ffn2_b2, s.b2, D));
+    EEC_HIP(cp(L.final_ln_w, p->group_ln_w[e], D));
+    EEC_HIP(cp(L.final_ln_b, p->group_ln_b[e], D));
   }
   EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
   EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
@@ -316,6 +366,41 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   }
   ++step;
   if (done()) return finish_dbg();
+
+  if (c.arch == EEC_ARCH_LEGACY) {
+    // Early_encoder: every key is valid (mask=None): overwrite the clamp(lengths/4) result with T'
+    EEC_HIP(launch_fill_int(ws.enc_len, B, Tq, st));
+    for (int e = 0; e < c.n_exits; ++e) {
+      for (int l = 0; l < c.layers_per_exit; ++l) {
+        const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
+        {
+          QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+          TIMED(KC_QKV, launch_qkv(a, np_o, st));
+          AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+          TIMED(KC_ATTN, launch_attention(at, np_o, st));
+          ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+          TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
+        }
+        ++step;
+        if (done()) return finish_dbg();
+        {
+          const bool last = l == c.layers_per_exit - 1;  // Encoder.layer_norm closes the group
+          FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2,
+                    last ? L.final_ln_w : nullptr, last ? L.final_ln_b : nullptr, 1.0f, true};
+          TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
+        }
+        ++step;
+        if (done()) return finish_dbg();
+      }
+      if (out) {
+        HeadArgs h{ws.x, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+        TIMED(KC_HEAD, launch_head(h, np_o, st));
+      }
+      if (taps_opt)
+        EEC_HIP(hipMemcpyAsync(taps_opt + (size_t)e * M * D, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return finish_dbg();
+  }
 
   for (int e = 0; e < c.n_exits; ++e) {
     for (int l = 0; l < c.layers_per_exit; ++l) {

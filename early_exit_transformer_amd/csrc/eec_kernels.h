@@ -13,6 +13,8 @@ struct FfnArgs {
   const uint4* w2p;  // packed W2 / log2(e) [256][F]
   const float* b2;
   const float *fin_g, *fin_b;  // optional final LayerNorm (nullptr = none)
+  float res_scale = 0.5f;      // x += res_scale * ffn(LN(x)): 0.5 Conformer half-step, 1.0 legacy layer
+  bool relu = false;           // legacy layer: ReLU, weights packed without the log2(e) fold
 };
 hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st);
 
@@ -88,13 +90,14 @@ struct SubsampleArgs {
 hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st);
 
 // weight packing (device -> device)
-hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // scale*W[N][K] -> fragments
+hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // out may point into a larger matrix: n-tile nt0 of [N'][K] starts at out + nt0*(K/16)*128  // scale*W[N][K] -> fragments
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
                           const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,
                           hipStream_t st);
 // conv weight [co][ci][3] -> fragments of the [co][3*ci_total] matrix with k ordered (j, ci)
 hipError_t launch_pack_conv_jci(const float* w, int cout, int cin, uint4* out, hipStream_t st);
+hipError_t launch_fill_int(int* dst, int n, int v, hipStream_t st);
 hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_len, hipStream_t st);
 
 // greedy CTC (argmax -> unique_consecutive -> drop blank)

@@ -73,8 +73,10 @@ extern "C" int eec_debug_ksteps(unsigned long long* out) {
 #define TL_STAMP()
 #endif
 
-template <int NP, bool FINAL_LN>
-__global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__ x, int M,
+// ACT 0: SiLU in the exp2 domain (Conformer; log2 e folded into the packed weights); ACT 1: ReLU (the
+// legacy pre-norm transformer layer, models/layers/position_wise_feed_forward.py:9-23, plain weights).
+template <int NP, bool FINAL_LN, int ACT>
+__global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__ x, int M, float res_scale,
                                                              const float* __restrict__ ln_g,
                                                              const float* __restrict__ ln_b,
                                                              const uint4* __restrict__ w1p,
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
     auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
       const int mt = step >> 3, q = step & 7;
-      const hl2_t sp = split2<NP>(silu_exp2(acc[mt][0][2 * q]), silu_exp2(acc[mt][0][2 * q + 1]));
+      const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
+      const hl2_t sp = ACT == 0 ? split2<NP>(silu_exp2(u0), silu_exp2(u1)) : split2<NP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
       if ((q & 1) == 0) {
         keep_hi = sp.hi;
         keep_lo = sp.lo;
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float4 e = *(const float4*)(smem + (w * 8 + i) * kELd + lane * 16);
-      v[i].x += 0.5f * e.x;
-      v[i].y += 0.5f * e.y;
-      v[i].z += 0.5f * e.z;
-      v[i].w += 0.5f * e.w;
+      v[i].x += res_scale * e.x;
+      v[i].y += res_scale * e.y;
+      v[i].z += res_scale * e.z;
+      v[i].w += res_scale * e.w;
     }
     if (FINAL_LN) layer_norm_rows<8>(v, g, bt);
 #pragma unroll
@@ -252,9 +255,9 @@ extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
 }
 #endif
 
-template <int NP, bool FL>
+template <int NP, bool FL, int ACT>
 static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {
-  auto k = ffn_kernel<NP, FL>;
+  auto k = ffn_kernel<NP, FL, ACT>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
@@ -262,15 +265,19 @@ static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {
     attr_done = true;
   }
   const int grid = (a.M + kTileRows - 1) / kTileRows;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), kFfnLds, st, a.x, a.M, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), kFfnLds, st, a.x, a.M, a.res_scale, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
                      a.b2, a.F, a.fin_g, a.fin_b);
   return hipGetLastError();
 }
 
 hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st) {
   const bool fl = a.fin_g != nullptr;
-  if (np == 3) return fl ? launch_ffn_t<3, true>(a, st) : launch_ffn_t<3, false>(a, st);
-  return fl ? launch_ffn_t<1, true>(a, st) : launch_ffn_t<1, false>(a, st);
+  if (a.relu) {
+    if (np == 3) return fl ? launch_ffn_t<3, true, 1>(a, st) : launch_ffn_t<3, false, 1>(a, st);
+    return fl ? launch_ffn_t<1, true, 1>(a, st) : launch_ffn_t<1, false, 1>(a, st);
+  }
+  if (np == 3) return fl ? launch_ffn_t<3, true, 0>(a, st) : launch_ffn_t<3, false, 0>(a, st);
+  return fl ? launch_ffn_t<1, true, 0>(a, st) : launch_ffn_t<1, false, 0>(a, st);
 }
 
 }  // namespace eec

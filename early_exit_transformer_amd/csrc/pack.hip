@@ -77,6 +77,16 @@ hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_
   return hipGetLastError();
 }
 
+__global__ void fill_int_kernel(int* dst, int n, int v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = v;
+}
+
+hipError_t launch_fill_int(int* dst, int n, int v, hipStream_t st) {
+  hipLaunchKernelGGL(fill_int_kernel, dim3((n + 63) / 64), dim3(64), 0, st, dst, n, v);
+  return hipGetLastError();
+}
+
 // Greedy CTC (reference util/beam_infer.py:9-24): argmax over labels, collapse repeats, drop blank.
 // One wave per sequence; frames are walked 64 at a time, kept tokens compacted with a ballot.
 // Ties in the argmax resolve to the lowest label index (torch.argmax on CPU).

@@ -56,7 +56,8 @@ class _HipEncoderMixin:
     precision = "f16x3"
 
     def _hip_init(self, d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len):
-        self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len)
+        self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len,
+                                   capi.ARCH_CONFORMER)
         self._enc = None
         self._packed_key = None
         self._ws: Dict[Tuple[int, int, int], Tensor] = {}
@@ -94,6 +95,10 @@ class _HipEncoderMixin:
                 raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {device}")
             return t.data_ptr()
 
+        self._pack(lib, device, sd, ptr)
+        self._packed_key = key
+
+    def _pack(self, lib, device, sd, ptr) -> None:
         E, L = self._cfg.n_exits, self._cfg.layers_per_exit
         layers = (capi.EecLayerParams * (E * L))()
         for e in range(E):
@@ -108,7 +113,6 @@ class _HipEncoderMixin:
                                 ptr(f"{self._pe_attr}.pe"), layers, hw, hb)
         stream = torch.cuda.current_stream(device).cuda_stream
         capi.check(lib.eec_encoder_pack(self._enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
-        self._packed_key = key
 
     # -- measurement hook -----------------------------------------------------
     def set_profiling(self, enable: bool, max_launches: int = 8192) -> None:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 1
+#define EEC_ABI_VERSION 2
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -46,7 +46,11 @@ typedef struct eec_config {
   int32_t n_mels;          /* features_length: 3*n_mels a multiple of 16, <= 384 (80 -> 240) */
   int32_t vocab;           /* dec_voc_size: multiple of 32, <= 256 */
   int32_t max_len;         /* rows of the positional-encoding table */
+  int32_t arch;            /* EEC_ARCH_CONFORMER (Early_conformer / full_conformer) or EEC_ARCH_LEGACY (Early_encoder) */
 } eec_config;
+
+#define EEC_ARCH_CONFORMER 0
+#define EEC_ARCH_LEGACY 1
 
 /* fp32 parameters of one torchaudio ConformerLayer, by state_dict key suffix. */
 typedef struct eec_layer_params {
@@ -75,6 +79,26 @@ typedef struct eec_params {
   const float* const* head_b;   /* HOST array of n_exits device pointers: linears.e.bias   [V]    */
 } eec_params;
 
+/* fp32 parameters of one legacy pre-norm transformer layer, models/blocks/encoder_layer.py:14-44 with
+ * models/layers/multi_head_attention.py:11-29 (separate w_q/w_k/w_v/w_concat Linears) and
+ * models/layers/position_wise_feed_forward.py:9-23 (Linear -> ReLU -> Linear); SURVEY.md 8a row a14. */
+typedef struct eec_legacy_layer_params {
+  const float *norm1_w, *norm1_b;                     /* norm1.{weight,bias}                 */
+  const float *wq, *bq, *wk, *bk, *wv, *bv, *wo, *bo; /* attention.w_{q,k,v,concat}.{weight,bias} [D,D],[D] */
+  const float *norm2_w, *norm2_b;                     /* norm2.{weight,bias}                 */
+  const float *w1, *b1, *w2, *b2;                     /* ffn.linear{1,2}.{weight,bias} [F,D],[F],[D,F],[D] */
+} eec_legacy_layer_params;
+
+/* Early_encoder (models/model/early_exit.py:497-562): stem, PE, E x Encoder(L layers + layer_norm), E heads. */
+typedef struct eec_legacy_params {
+  const float *sub0_w, *sub0_b, *sub1_w, *sub1_b, *pe;
+  const eec_legacy_layer_params* layers; /* HOST array, n_exits*layers_per_exit, exit-major: encoders.e.layers.l */
+  const float* const* group_ln_w;        /* HOST arrays of n_exits device pointers: encoders.e.layer_norm.{weight,bias} */
+  const float* const* group_ln_b;
+  const float* const* head_w;            /* linears.e.{weight,bias} */
+  const float* const* head_b;
+} eec_legacy_params;
+
 typedef struct eec_encoder eec_encoder;
 
 const char* eec_last_error(void);
@@ -92,6 +116,10 @@ void eec_encoder_destroy(eec_encoder* enc);
  * BatchNorm semantics (running statistics).  Asynchronous on `stream`. */
 int eec_encoder_pack(eec_encoder* enc, const eec_params* params, void* stream);
 
+/* Same for an EEC_ARCH_LEGACY encoder (no mask, no convolution module; `lengths` of eec_encoder_forward is ignored:
+ * Early_encoder.forward(src) passes mask=None, early_exit.py:549-554). */
+int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* params, void* stream);
+
 size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T);
 
 /* Replaces Early_conformer.forward(src, lengths) (early_exit.py:617-634) in eval mode:
@@ -100,7 +128,7 @@ size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T);
  *   taps_opt [E, B, T', D] fp32 or NULL: pre-head activations after each exit group
  *            (what full_conformer._encoder_(src, lengths, n) returns, early_exit.py:719-737)
  *   stop_after: <0 = run everything; otherwise stop after that many sub-steps
- *            (0 = stem, then per layer: ffn1, attention, conv, ffn2) -- test hook; the current
+ *            (0 = stem, then per layer: ffn1, attention, conv, ffn2; legacy: attention, ffn) -- test hook; the current
  *            residual stream is then left in x_dbg_opt [B*T', D] if given. */
 int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T,
                         int precision, float* out, float* taps_opt, void* workspace, size_t workspace_bytes,

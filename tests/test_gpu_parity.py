@@ -39,7 +39,7 @@ def run_gpu(model, mel, lens, prec="f16x3"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 1
+    assert lib.eec_abi_version() == 2
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
@@ -192,6 +192,39 @@ def test_exit_ctc_losses_match_torch_ctc(E, B, T, V, S):
     want = torch.stack([ctc(logp[e].permute(1, 0, 2), tgt, il, tl) for e in range(E)])
     assert torch.allclose(got, want, rtol=2e-5, atol=2e-5), (got, want)
     assert abs(got.sum().item() - R.summed_exit_ctc_loss(logp, tgt, tl).item()) < 1e-4 * max(1.0, want.sum().item())
+
+
+@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+def test_legacy_early_encoder_golden(prec):
+    """the legacy pre-norm transformer encoder on the same kernels (attention without mask,
+    ReLU feed-forward, group-final LayerNorm); fixture produced by the reference's own, unmodified Early_encoder."""
+    from early_exit_transformer_amd.legacy import Early_encoder
+    z, kw = load_golden("legacy_small")
+    kw.pop("depthwise_kernel_size")
+    m = Early_encoder(**{**kw, "device": "cuda"}).eval()
+    m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=int(z["seed"]), style="trained"), strict=True)
+    m = m.cuda()
+    m.precision = prec
+    with torch.no_grad():
+        out = m(synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"])).cuda()).cpu()
+    assert out.shape == z["logp"].shape
+    assert np.abs(out.numpy() - z["logp"]).max() < TOL[prec]
+
+
+def test_legacy_early_encoder_against_oracle_other_shapes():
+    from early_exit_transformer_amd.legacy import Early_encoder
+    from oracle import legacy_ref as LR
+    kw = base_kwargs(n_enc_exits=1, n_enc_layers=3, d_feed_forward=512, n_head=4)
+    kw.pop("depthwise_kernel_size")
+    ref = LR.EarlyEncoderRef(**kw).eval()
+    sd = synth.synth_state_dict(ref.state_dict(), seed=8, style="trained")
+    ref.load_state_dict(sd)
+    m = Early_encoder(**{**kw, "device": "cuda"}).eval()
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    mel = synth.synth_mel(2, 80, 403, seed=8)
+    with torch.no_grad():
+        assert (m(mel.cuda()).cpu() - ref(mel)).abs().max().item() < TOL["f16x3"]
 
 
 def test_reload_weights_repacks():

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
     assert set(capi.EXPORTS) == declared
-    assert lib.eec_abi_version() == 1
+    assert lib.eec_abi_version() == 2
 
 
 def test_out_frames_matches_conv_arithmetic(lib):
@@ -46,7 +46,7 @@ def test_out_frames_matches_conv_arithmetic(lib):
                                               ("dw_kernel", 32, 10002), ("dw_kernel", 33, 10002), ("vocab", 300, 10002),
                                               ("n_exits", 0, 10001)])
 def test_create_rejects_unsupported_configs_before_touching_the_gpu(lib, field, value, code):
-    cfg = capi.EecConfig(256, 8, 2048, 31, 6, 2, 80, 256, 2000)
+    cfg = capi.EecConfig(256, 8, 2048, 31, 6, 2, 80, 256, 2000, 0)
     setattr(cfg, field, value)
     h = C.c_void_p()
     assert lib.eec_encoder_create(C.byref(cfg), C.byref(h)) == code
