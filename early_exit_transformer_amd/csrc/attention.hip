@@ -82,44 +82,65 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
     __syncthreads();
     if (!active) continue;
     const int nkt = (min(len - kc0, kKC) + 31) / 32;
-    for (int kt = 0; kt < nkt; ++kt) {
-      f32x16 s;
+    // online softmax over blocks of KB = 4 key tiles (128 keys): the per-block overhead (cross-half
+    // max, rescale of O, running sums) is paid once per 128 keys; the key mask is applied only in a
+    // block that actually contains keys >= len (wave-uniform test)
+    constexpr int KB = 4;
+    for (int kt0 = 0; kt0 < nkt; kt0 += KB) {
+      f32x16 s[KB];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[i] = 0.f;
+      for (int j = 0; j < KB; ++j) {
 #pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) {
-        const h8 kf = *(const h8*)(lds_k + (kt * 32 + r) * L::KLD + (ks * 16 + 8 * hh) * 2);
-        s = mfma16(kf, qf[ks], s);
+        for (int i = 0; i < 16; ++i) s[j][i] = 0.f;
+        if (kt0 + j < nkt) {  // wave-uniform
+#pragma unroll
+          for (int ks = 0; ks < KSQ; ++ks) {
+            const h8 kf = *(const h8*)(lds_k + ((kt0 + j) * 32 + r) * L::KLD + (ks * 16 + 8 * hh) * 2);
+            s[j] = mfma16(kf, qf[ks], s[j]);
+          }
+        }
       }
-      const int key0 = kc0 + kt * 32;
+      const int key0 = kc0 + kt0 * 32;
+      if (key0 + KB * 32 > len) {  // block touches the masked tail (or runs past the last tile)
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            if (key0 + j * 32 + acc_row(i, lane) >= len) s[j][i] = kNegBig;
+      }
       float tmax = kNegBig;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        if (key0 + acc_row(i, lane) >= len) s[i] = kNegBig;
-        tmax = fmaxf(tmax, s[i]);
-      }
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, s[j][i]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       float psum = 0.f;
-      h8 pf[2];
+      h8 pf[KB][2];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float p = __builtin_amdgcn_exp2f(s[i] - m_new);
-        psum += p;
-        pf[i >> 3][i & 7] = (half_t)p;
-      }
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(s[j][i] - m_new);
+          psum += p;
+          pf[j][i >> 3][i & 7] = (half_t)p;
+        }
       l_run = l_run * alpha + psum;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          const h8 vf = *(const h8*)(lds_v + (dt * 32 + r) * L::VLD + (kt * 32 + ks * 16 + 8 * hh) * 2);
-          o[dt] = mfma16(vf, pf[ks], o[dt]);
-        }
+        for (int j = 0; j < KB; ++j)
+          if (kt0 + j < nkt) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+              const h8 vf = *(const h8*)(lds_v + (dt * 32 + r) * L::VLD + ((kt0 + j) * 32 + ks * 16 + 8 * hh) * 2);
+              o[dt] = mfma16(vf, pf[j][ks], o[dt]);
+            }
+          }
       }
     }
   }

@@ -60,7 +60,7 @@ size_t frag_u4(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 128; 
 
 }  // namespace
 
-enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ, KC_GLU, KC_DW, KC_HEAD, KC_COUNT };
+enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, KC_DW_PW2, KC_HEAD, KC_COUNT };
 
 struct eec_encoder {
   eec_config cfg;
@@ -424,7 +424,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
         if (split_here) {
           TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
         } else {
-          TIMED(KC_PROJ, launch_proj_glu(pr, ga, np_o, st));
+          TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
         }
         ++step;
         if (done()) return finish_dbg();
@@ -432,7 +432,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       {
         DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
         ProjResArgs pr{ws.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
-        TIMED(KC_DW, launch_dw_pw2(da, pr, np_o, st));
+        TIMED(KC_DW_PW2, launch_dw_pw2(da, pr, np_o, st));
       }
       ++step;
       if (done()) return finish_dbg();

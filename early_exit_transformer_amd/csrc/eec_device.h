@@ -3,7 +3,7 @@
 // Conventions used by every kernel in this directory
 // ---------------------------------------------------
 // * A "row tile" is 64 consecutive rows of the flattened (utterance x frame)
-//   axis M = B*T'.  One 256-thread workgroup (4 waves, one per SIMD) owns one
+//   axis M = B*T'.  One 512-thread workgroup (8 waves, two per SIMD) owns one
 //   row tile and all of the output columns of it; M/64 = 256 tiles at the
 //   headline shape = one workgroup per CU.
 // * 16-bit operands are fp16.  "NP" = number of MFMA passes per product:
@@ -114,84 +114,12 @@ __device__ __forceinline__ float silu_exp2(float u) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 // row of accumulator register i for this lane (within a 32x32 tile)
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
-
-// ---------------------------------------------------------------------------
-// One GEMM stage: acc[MT][NT] += Act(LDS planes) x W(packed, global).
-//   lds_act   : byte address of plane 0, row 0 of the activation tile
-//   ld_bytes  : row stride, plane_bytes: distance hi -> lo plane
-//   wfrag     : packed weights; fragment (nt, s) at wfrag[((nt*ks_total + s)*2 + p)*64 + lane]
-//   nt0       : first n-tile of this wave, s0: first k-step of W, KS steps are consumed;
-//               activation k starts at column 0 of the LDS tile.
-//   SWAP      : false -> acc[mt][nt] is [m rows][n lanes]; true -> [n rows][m lanes]
-// Weight fragments are prefetched PF k-steps ahead in registers.
-// ---------------------------------------------------------------------------
-template <int NP, int KS, int MT, int NT, bool SWAP, int PF = 2>
-__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[MT][NT], const char* lds_act, int ld_bytes,
-                                           int plane_bytes, const uint4* __restrict__ wfrag,
-                                           int ks_total, int nt0, int s0) {
-  const int lane = lane_id();
-  constexpr int NPL = (NP == 3) ? 2 : 1;
-  const char* a_ptr = lds_act + (lane & 31) * ld_bytes + (lane >> 5) * 16;
-  const uint4* w_ptr = wfrag + ((size_t)(nt0 * ks_total + s0) * 2) * 64 + lane;
-  const size_t nt_stride = (size_t)ks_total * 2 * 64;
-
-  uint4 wq[PF][NT][NPL];
-#pragma unroll
-  for (int p = 0; p < PF; ++p)
-    if (p < KS) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) wq[p][nt][pl] = w_ptr[nt * nt_stride + (size_t)(p * 2 + pl) * 64];
-    }
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    h8 ah[MT], al[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      ah[mt] = *(const h8*)(a_ptr + mt * 32 * ld_bytes + s * 32);
-      if (NP == 3) al[mt] = *(const h8*)(a_ptr + plane_bytes + mt * 32 * ld_bytes + s * 32);
-    }
-    h8 bh[NT], bl[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      bh[nt] = __builtin_bit_cast(h8, wq[s % PF][nt][0]);
-      if (NP == 3) bl[nt] = __builtin_bit_cast(h8, wq[s % PF][nt][NPL - 1]);
-    }
-    if (s + PF < KS) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl)
-          wq[s % PF][nt][pl] = w_ptr[nt * nt_stride + (size_t)((s + PF) * 2 + pl) * 64];
-    }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        if (!SWAP) {
-          if (NP == 3) {
-            acc[mt][nt] = mfma16(al[mt], bh[nt], acc[mt][nt]);
-            acc[mt][nt] = mfma16(ah[mt], bl[nt], acc[mt][nt]);
-          }
-          acc[mt][nt] = mfma16(ah[mt], bh[nt], acc[mt][nt]);
-        } else {
-          if (NP == 3) {
-            acc[mt][nt] = mfma16(bh[nt], al[mt], acc[mt][nt]);
-            acc[mt][nt] = mfma16(bl[nt], ah[mt], acc[mt][nt]);
-          }
-          acc[mt][nt] = mfma16(bh[nt], ah[mt], acc[mt][nt]);
-        }
-      }
-  }
-}
 
 // ---------------------------------------------------------------------------
 // Register ring of weight fragments: the first PF k-steps of a stage are loaded by the caller
@@ -453,27 +381,6 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
       *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
       if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
     }
-  }
-}
-
-// fp16 planes in global ([M][256] hi, [M][256] lo) -> LDS planes.
-template <int NP>
-__device__ __forceinline__ void rows_planes_to_lds(char* lds_act, const half_t* __restrict__ hi,
-                                                   const half_t* __restrict__ lo, int row0, int M) {
-  const int t = threadIdx.x;
-  // 64 rows x 512 B per plane = 2048 16-byte pieces; 256 threads x 8
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int piece = it * kThreads + t;
-    const int rl = piece >> 5, c16 = piece & 31;
-    const int row = row0 + rl;
-    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
-    if (row < M) {
-      vh = *(const uint4*)(hi + (size_t)row * kD + c16 * 8);
-      if (NP == 3) vl = *(const uint4*)(lo + (size_t)row * kD + c16 * 8);
-    }
-    *(uint4*)(lds_act + rl * kALd + c16 * 16) = vh;
-    if (NP == 3) *(uint4*)(lds_act + kAPlane + rl * kALd + c16 * 16) = vl;
   }
 }
 

@@ -28,7 +28,7 @@ struct QkvArgs {
 };
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
-struct ProjResArgs {  // x += planes . W^T + bias   (attention out-proj, conv pointwise-2)
+struct ProjResArgs {  // x += planes . W^T + bias   (attention out-proj; also the GEMM half of dw_pw2 / proj_glu)
   float* x;
   int M;
   const half_t *a_hi, *a_lo;  // [M][256]
@@ -45,7 +45,6 @@ struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,256), gate cols [25
   const float* bias;
   half_t* g;  // [M][256] fp16
 };
-hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st);
 // fused: attention out-proj + residual -> conv LayerNorm -> pointwise-1 -> GLU (g.x is ignored: rows come from a.x)
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st);
 
@@ -71,7 +70,7 @@ struct DwArgs {
   int B, Tq;
   const float* wfold;  // [31][256] taps (BN folded, zero padded to 31, centred)
   const float* bfold;  // [256]
-  half_t *o_hi, *o_lo;
+  half_t *o_hi, *o_lo;  // unused by the fused kernel (kept for layout compatibility of the argument block)
 };
 // fused depthwise conv + BN + SiLU -> pointwise-2 + residual (o_hi/o_lo of DwArgs are unused)
 hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st);

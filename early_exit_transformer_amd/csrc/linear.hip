@@ -6,7 +6,7 @@
 // is filled during the previous pass (or the prologue).  Accumulators start at the bias.
 //   qkv_kernel           LN -> in_proj (N=768) -> Q (pre-scaled), K, V^T in attention layouts   
 //   proj_residual_kernel x += A . W^T + b   (attention out_proj a6; conv pointwise-2 a7)
-//   pw1_glu_kernel       LN -> pointwise-1 (N=512) -> GLU -> fp16                                  (a7)
+//   proj_glu_kernel      out_proj + residual -> LN -> pointwise-1 (N=512) -> GLU -> fp16, one launch (a6, a7)
 //   head_kernel          exit head: Linear(D,V) -> log_softmax -> fp32 log-probs                    (a9)
 #include "eec_kernels.h"
 
@@ -209,51 +209,6 @@ hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st) {
   hipError_t e = set_lds_once(k, LDS, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + ROWS - 1) / ROWS), dim3(kLinThreads), LDS, st, a);
-  return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-template <int NP>
-__global__ __launch_bounds__(kLinThreads, 2) void pw1_glu_kernel(GluArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
-  const int row0 = blockIdx.x * kTileRows;
-  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
-  WRing<NP, kLPF> rv, rg;
-  ring_fill<NP, kLPF, 1>(rv, wfrag_lane(a.wp, w), 0, kD / 16);
-  rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
-  __syncthreads();
-  ring_fill<NP, kLPF, 1>(rg, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
-  f32x16 av[2][1], ag[2][1];
-  acc_init_bias<2>(av, a.bias + 32 * w);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rv);
-  acc_init_bias<2>(ag, a.bias + kD + 32 * w);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rg);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int row = row0 + mt * 32 + (lane & 31);
-    if (row < a.M) {
-      half_t* dst = a.g + (size_t)row * kD + 32 * w + 4 * hh;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        h4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float gate = ag[mt][0][4 * g + j];
-          o[j] = to_half_sat(av[mt][0][4 * g + j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * gate)));
-        }
-        *(h4*)(dst + 8 * g) = o;
-      }
-    }
-  }
-}
-
-hipError_t launch_pw1_glu(const GluArgs& a, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
-  auto k = np == 3 ? pw1_glu_kernel<3> : pw1_glu_kernel<1>;
-  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
   return hipGetLastError();
 }
 
