@@ -8,9 +8,9 @@ from typing import Optional
 
 from .build import LIB_PATH
 
-PREC_F16X3, PREC_MIXED, PREC_F16 = 0, 1, 2
+PREC_F16X3, PREC_MIXED, PREC_F16, PREC_F16F8 = 0, 1, 2, 3
 ARCH_CONFORMER, ARCH_LEGACY = 0, 1
-PRECISIONS = {"f16x3": PREC_F16X3, "mixed": PREC_MIXED, "f16": PREC_F16}
+PRECISIONS = {"f16x3": PREC_F16X3, "mixed": PREC_MIXED, "f16": PREC_F16, "f16f8": PREC_F16F8}
 
 _LAYER_FIELDS = [
     "ffn1_ln_w", "ffn1_ln_b", "ffn1_w1", "ffn1_b1", "ffn1_w2", "ffn1_b2",

@@ -32,13 +32,13 @@ int hip_fail(hipError_t e, const char* what) {
 struct PackedLayer {
   // device pointers into the encoder's arena
   float *ffn1_ln_w, *ffn1_ln_b, *ffn1_b1, *ffn1_b2;
-  uint4 *ffn1_w1p, *ffn1_w2p;
+  uint4 *ffn1_w1p, *ffn1_w2p, *ffn1_w1f8, *ffn1_w2f8;
   float *attn_ln_w, *attn_ln_b, *attn_in_b, *attn_out_b;
   uint4 *attn_in_p, *attn_out_p;
   float *conv_ln_w, *conv_ln_b, *conv_pw1_b, *conv_pw2_b, *dw_wfold, *dw_bfold;
   uint4 *conv_pw1_p, *conv_pw2_p;
   float *ffn2_ln_w, *ffn2_ln_b, *ffn2_b1, *ffn2_b2;
-  uint4 *ffn2_w1p, *ffn2_w2p;
+  uint4 *ffn2_w1p, *ffn2_w2p, *ffn2_w1f8, *ffn2_w2f8;
   float *final_ln_w, *final_ln_b;
 };
 
@@ -57,6 +57,7 @@ struct Arena {  // bump allocator over one hipMalloc
 };
 
 size_t frag_u4(int N, int K) { return (size_t)((N + 31) / 32) * (K / 16) * 128; }
+size_t f8_u4(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 63) / 64) * kF8Rec; }
 
 }  // namespace
 
@@ -89,6 +90,8 @@ struct eec_encoder {
       L.ffn1_b2 = arena.take<float>(D);
       L.ffn1_w1p = arena.take<uint4>(frag_u4(F, D));
       L.ffn1_w2p = arena.take<uint4>(frag_u4(D, F));
+      L.ffn1_w1f8 = arena.take<uint4>(f8_u4(F, D));
+      L.ffn1_w2f8 = arena.take<uint4>(f8_u4(D, F));
       L.attn_ln_w = arena.take<float>(D);
       L.attn_ln_b = arena.take<float>(D);
       L.attn_in_b = arena.take<float>(3 * D);
@@ -109,6 +112,8 @@ struct eec_encoder {
       L.ffn2_b2 = arena.take<float>(D);
       L.ffn2_w1p = arena.take<uint4>(frag_u4(F, D));
       L.ffn2_w2p = arena.take<uint4>(frag_u4(D, F));
+      L.ffn2_w1f8 = arena.take<uint4>(f8_u4(F, D));
+      L.ffn2_w2f8 = arena.take<uint4>(f8_u4(D, F));
       L.final_ln_w = arena.take<float>(D);
       L.final_ln_b = arena.take<float>(D);
     }
@@ -232,6 +237,10 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.ffn1_b2, s.ffn1_b2, D));
     EEC_HIP(launch_pack_frags(s.ffn1_w1, F, D, L.ffn1_w1p, kLog2e, st));
     EEC_HIP(launch_pack_frags(s.ffn1_w2, D, F, L.ffn1_w2p, 1.0f / kLog2e, st));
+    if (F % 128 == 0) {
+      EEC_HIP(launch_pack_frags_f8(s.ffn1_w1, F, D, L.ffn1_w1f8, kLog2e, st));
+      EEC_HIP(launch_pack_frags_f8(s.ffn1_w2, D, F, L.ffn1_w2f8, 1.0f / kLog2e, st));
+    }
     EEC_HIP(cp(L.attn_ln_w, s.attn_ln_w, D));
     EEC_HIP(cp(L.attn_ln_b, s.attn_ln_b, D));
     EEC_HIP(cp(L.attn_in_b, s.attn_in_b, 3 * D));
@@ -252,6 +261,10 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.ffn2_b2, s.ffn2_b2, D));
     EEC_HIP(launch_pack_frags(s.ffn2_w1, F, D, L.ffn2_w1p, kLog2e, st));
     EEC_HIP(launch_pack_frags(s.ffn2_w2, D, F, L.ffn2_w2p, 1.0f / kLog2e, st));
+    if (F % 128 == 0) {
+      EEC_HIP(launch_pack_frags_f8(s.ffn2_w1, F, D, L.ffn2_w1f8, kLog2e, st));
+      EEC_HIP(launch_pack_frags_f8(s.ffn2_w2, D, F, L.ffn2_w2f8, 1.0f / kLog2e, st));
+    }
     EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
   }
@@ -299,6 +312,10 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
     EEC_HIP(launch_pack_frags(s.w1, F, D, L.ffn2_w1p, 1.0f, st));
     EEC_HIP(cp(L.ffn2_b1, s.b1, F));
     EEC_HIP(launch_pack_frags(s.w2, D, F, L.ffn2_w2p, 1.0f, st));
+    if (F % 128 == 0) {
+      EEC_HIP(launch_pack_frags_f8(s.w1, F, D, L.ffn2_w1f8, 1.0f, st));
+      EEC_HIP(launch_pack_frags_f8(s.w2, D, F, L.ffn2_w2f8, 1.0f, st));
+    }
     EEC_HIP(cp(L.ffn2_b2, s.b2, D));
     EEC_HIP(cp(L.final_ln_w, p->group_ln_w[e], D));
     EEC_HIP(cp(L.final_ln_b, p->group_ln_b[e], D));
@@ -328,7 +345,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   if (!out && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "out is null");
   if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
   if (B <= 0 || T < 7) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 7 (two k=3 s=2 convs)");
-  if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16) return fail(EEC_ERR_BAD_ARG, "unknown precision");
+  if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
   const eec_config& c = enc->cfg;
   const int T1 = (T - 3) / 2 + 1, Tq = (T1 - 3) / 2 + 1, Tp = (Tq + 31) / 32 * 32;
   if (Tq > c.max_len) return fail(EEC_ERR_BAD_ARG, "T' exceeds the positional-encoding table (max_len)");
@@ -336,7 +353,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   Workspace ws = carve_ws(c, B, T, (char*)workspace);
   if (workspace_bytes < ws.bytes) return fail(EEC_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : 1;
+  const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
   const int M = B * Tq, D = c.d_model, H = c.n_heads;
   int step = 0;
@@ -387,6 +404,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
           const bool last = l == c.layers_per_exit - 1;  // Encoder.layer_norm closes the group
           FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2,
                     last ? L.final_ln_w : nullptr, last ? L.final_ln_b : nullptr, 1.0f, true};
+          a.w1f8 = L.ffn2_w1f8, a.w2f8 = L.ffn2_w2f8;
           TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
         }
         ++step;
@@ -407,6 +425,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
       {
         FfnArgs a{ws.x, M, c.d_ff, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr};
+        a.w1f8 = L.ffn1_w1f8, a.w2f8 = L.ffn1_w2f8;
         TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
       ++step;
@@ -438,6 +457,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (done()) return finish_dbg();
       {
         FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b};
+        a.w1f8 = L.ffn2_w1f8, a.w2f8 = L.ffn2_w2f8;
         TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
       ++step;

@@ -50,6 +50,7 @@ constexpr float kHalfMax = 65504.0f;
 // "32 different rows, same column" conflict-free (stride = 4 banks mod 64).
 constexpr int kALd = (kD + 8) * 2;            // 528  : [64][256] fp16 activation plane
 constexpr int kAPlane = kTileRows * kALd;     // 33792
+constexpr int kA8Ld = kD + 16;                // 272  : [64][256] e5m2 byte plane (NP == 8), row pad keeps b128 reads conflict-free
 constexpr int kELd = (kD + 4) * 4;            // 1040 : [64][256] fp32 epilogue tile
 constexpr int kETile = kTileRows * kELd;      // 66560 (aliases the two A planes: 67584)
 
@@ -295,6 +296,146 @@ __device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][1], const char*
   }
 }
 
+// ===========================================================================
+// NP == 8: "fp16 + 2 x fp8-correction" product.
+//   a.w  ~=  a_hi.w_hi  (v_mfma_f32_32x32x16_f16)
+//          + a_lo8.w_hi8 + a_hi8.w_lo8  (v_mfma_scale_f32_32x32x64_f8f6f4, bf8 = e5m2 operands, 2x the fp16 rate)
+// The two correction terms are ~2^-11 of the main term, so 3 significant bits in their operands keep the
+// product good to ~13-14 bits: measured |dlogp| 2.9e-4 (FFN only) against 2.4e-4 for the exact 3-pass split.
+// e5m2 is the top byte of an fp16, so a_hi8 / w_hi8 are byte-permutes of the fp16 fragments already in
+// registers; a_lo8 is a byte plane in LDS; w_lo8 is packed per weight with an E8M0 block scale (the weight
+// residuals are fp16-subnormal: the block scale of the MX instruction is what makes them representable).
+// Hardware layout of the K=64 instruction (tools/mx_probe.hip): lane l holds row/col l%32; its 32 bytes pair
+// element-wise between A and B, so any consistent k <-> byte-slot map works; bytes 0-15 / 16-31 of a lane form
+// scale blocks 0 / 1 (together with the same bytes of lane l^32), and the scale of block b comes from lane r+32b.
+// Slot map used here: byte p of lane half h of a 64-k group  <->  k = 16*(p/8) + 8*h + p%8, i.e. the concatenation
+// of the lane's four fp16 k-step fragments; a scale block is then two consecutive k-steps (32 consecutive k).
+// ===========================================================================
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+constexpr int kE8M0One = 127;
+
+// top bytes (e5m2) of the 8 halves of an fp16 fragment -> 8 bytes
+__device__ __forceinline__ uint2 top_bytes(uint4 f) {
+  return make_uint2(__builtin_amdgcn_perm(f.y, f.x, 0x07050301u), __builtin_amdgcn_perm(f.w, f.z, 0x07050301u));
+}
+__device__ __forceinline__ f32x16 mfma_f8(i32x8 a, i32x8 b, f32x16 c, int scale_a, int scale_b) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1 /*A: bf8*/, 1 /*B: bf8*/, 0, scale_a, 0, scale_b);
+}
+// byte position of activation column k inside the permuted lo8 plane row (64-k groups, see slot map)
+__device__ __forceinline__ int lo8_pos(int k) {
+  return (k & ~63) + 32 * ((k >> 3) & 1) + 8 * ((k >> 4) & 3) + (k & 7);
+}
+
+// Packed "f8" weight stream: per (n-tile, 64-k group) one record of 400 uint4:
+//   [4 hi fragments x 64 lanes][lo8: 64 lanes x 2 uint4][scale: 64 lanes x 1 dword (64 B used of 256)]
+constexpr int kF8Rec = 400;
+template <int NT>
+struct WGroupF8 {      // lo8 + scale of ONE 64-k group for NT n-tiles
+  uint4 lo[NT][2];
+  int sc[NT];
+};
+template <int NT>
+__device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __restrict__ rec_lane, size_t nt_stride) {
+  // rec_lane = record base + lane
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const uint4* r = rec_lane + nt * nt_stride - lane_id();
+    g.lo[nt][0] = r[256 + 2 * lane_id()];
+    g.lo[nt][1] = r[256 + 2 * lane_id() + 1];
+    g.sc[nt] = ((const int*)(r + 384))[lane_id()];
+  }
+}
+
+// acc[2][NT] += Act x W over NG 64-k groups.  a_lane / a8_lane: this lane's fp16-hi and byte-lo8 LDS pointers
+// (row l%32, half l/32); rec_lane: first record (+lane); consecutive groups are kF8Rec uint4 apart.
+// hi fragments run through the register ring `r` (PF k-steps ahead, as gemm_ring); the lo8/scale blocks of
+// the whole stage are in `wg` (loaded by the caller one stage ahead).
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0>
+__device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
+                                             int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
+                                             WRing<1, PF, NT>& r, const WGroupF8<NT> (&wg)[NG], Side side = Side()) {
+  constexpr int KS = 4 * NG;
+  auto hi_addr = [&](int s) { return (size_t)(s >> 2) * kF8Rec + (size_t)(s & 3) * 64; };
+  h8 ah[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
+  uint2 a8[2][4];   // [mt][step in group]: e5m2 of the activation hi fragments
+  uint2 w8[NT][4];  // [nt][step in group]: e5m2 of the weight hi fragments
+  i32x8 alo[2];     // activation lo8 of the current group
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1, q = s & 3, g = s >> 2;
+    if (s + 1 < KS) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
+    }
+    if (q == 0) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const uint4 l0 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64);
+        const uint4 l1 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64 + 16);
+        alo[mt] = (i32x8){(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) a8[mt][q] = top_bytes(__builtin_bit_cast(uint4, ah[cur][mt]));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint4 wq = r.q[s % PF][nt][0];
+      w8[nt][q] = top_bytes(wq);
+      const h8 bh = __builtin_bit_cast(h8, wq);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        acc[mt][nt] = SWAP ? mfma16(bh, ah[cur][mt], acc[mt][nt]) : mfma16(ah[cur][mt], bh, acc[mt][nt]);
+    }
+    if (s + PF < KS) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = rec_lane[nt * nt_stride + hi_addr(s + PF)];
+    }
+    if (q == 3) {  // the group's two correction products
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const i32x8 whi = {(int)w8[nt][0].x, (int)w8[nt][0].y, (int)w8[nt][1].x, (int)w8[nt][1].y,
+                           (int)w8[nt][2].x, (int)w8[nt][2].y, (int)w8[nt][3].x, (int)w8[nt][3].y};
+        const i32x8 wlo = {(int)wg[g].lo[nt][0].x, (int)wg[g].lo[nt][0].y, (int)wg[g].lo[nt][0].z, (int)wg[g].lo[nt][0].w,
+                           (int)wg[g].lo[nt][1].x, (int)wg[g].lo[nt][1].y, (int)wg[g].lo[nt][1].z, (int)wg[g].lo[nt][1].w};
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const i32x8 ahi = {(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
+                             (int)a8[mt][2].x, (int)a8[mt][2].y, (int)a8[mt][3].x, (int)a8[mt][3].y};
+          if (SWAP) {
+            acc[mt][nt] = mfma_f8(whi, alo[mt], acc[mt][nt], kE8M0One, kE8M0One);
+            acc[mt][nt] = mfma_f8(wlo, ahi, acc[mt][nt], wg[g].sc[nt], kE8M0One);
+          } else {
+            acc[mt][nt] = mfma_f8(alo[mt], whi, acc[mt][nt], kE8M0One, kE8M0One);
+            acc[mt][nt] = mfma_f8(ahi, wlo, acc[mt][nt], kE8M0One, wg[g].sc[nt]);
+          }
+        }
+      }
+    }
+    side(s);
+    if (SIDE_VALU > 0) {
+#pragma unroll
+      for (int i = 0; i < 2 * NT; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, SIDE_VALU, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// ring fill for the f8 stream: hi fragments of the first PF k-steps of a stage
+template <int PF, int NT>
+__device__ __forceinline__ void ring_fill_f8(WRing<1, PF, NT>& r, const uint4* __restrict__ rec_lane, size_t nt_stride) {
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) r.q[p][nt][0] = rec_lane[nt * nt_stride + (size_t)(p >> 2) * kF8Rec + (size_t)(p & 3) * 64];
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -375,11 +516,15 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
     for (int i = 0; i < NB; ++i) {
       const int rl = w * RPW + b0 + i;
       if (DO_LN && row0 + rl >= M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const hl2_t s0 = split2<NP>(v[i].x, v[i].y), s1 = split2<NP>(v[i].z, v[i].w);
+      const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(v[i].x, v[i].y), s1 = split2<(NP == 1 ? 1 : 3)>(v[i].z, v[i].w);
       h4 hi, lo;
       hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
       *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
       if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
+      if (NP == 8) {  // e5m2 bytes of the lo halves, permuted to the MX slot order
+        const uint2 lb = __builtin_bit_cast(uint2, lo);
+        *(unsigned*)(lds_act + kAPlane + rl * kA8Ld + lo8_pos(lane * 4)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+      }
     }
   }
 }

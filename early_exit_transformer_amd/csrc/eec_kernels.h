@@ -15,6 +15,7 @@ struct FfnArgs {
   const float *fin_g, *fin_b;  // optional final LayerNorm (nullptr = none)
   float res_scale = 0.5f;      // x += res_scale * ffn(LN(x)): 0.5 Conformer half-step, 1.0 legacy layer
   bool relu = false;           // legacy layer: ReLU, weights packed without the log2(e) fold
+  const uint4 *w1f8 = nullptr, *w2f8 = nullptr;  // the same two matrices in the NP == 8 stream layout (optional)
 };
 hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st);
 
@@ -90,6 +91,7 @@ hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st);
 
 // weight packing (device -> device)
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // out may point into a larger matrix: n-tile nt0 of [N'][K] starts at out + nt0*(K/16)*128  // scale*W[N][K] -> fragments
+hipError_t launch_pack_frags_f8(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // NP == 8 stream (K % 64 == 0)
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
                           const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,

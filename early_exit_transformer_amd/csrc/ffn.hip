@@ -43,6 +43,12 @@ constexpr int kFfnLds = 2 * kAPlane + 4 * kHPlane;  // A hi/lo + per-group H hi/
 #endif
 template <int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = EEC_PF2_NP3; };
 template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF2_NP1; };
+#ifndef EEC_PF1_NP8
+#define EEC_PF1_NP8 6
+#define EEC_PF2_NP8 3
+#endif
+template <> struct FfnPf<8> { static constexpr int P1 = EEC_PF1_NP8, P2 = EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+constexpr int kH8Ld = kFC + 16;  // 144: H lo8 byte plane row stride (NP == 8)
 
 #ifdef EEC_TIMELINE
 // Diagnostic build only: s_memtime stamps of wave 0 (producer) and wave 4 (consumer) of the first
@@ -84,7 +90,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
                                                              const uint4* __restrict__ w2p,
                                                              const float* __restrict__ b2, int F,
                                                              const float* __restrict__ fin_g,
-                                                             const float* __restrict__ fin_b) {
+                                                             const float* __restrict__ fin_b,
+                                                             const uint4* __restrict__ w1f8,
+                                                             const uint4* __restrict__ w2f8) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kPF1 = FfnPf<NP>::P1, kPF2 = FfnPf<NP>::P2;
   const int lane = lane_id(), w = wave_id();
@@ -103,13 +111,38 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
   int tl_idx = 0;
 #endif
   TL_STAMP();  // 0: kernel entry
-  WRing<NP, kPF1, 1> r1;
-  WRing<NP, kPF2, 2> r2;
+  constexpr int RNP = NP == 8 ? 1 : NP;  // the f8 stream keeps only the hi fragments in the ring
+  WRing<RNP, kPF1, 1> r1;
+  WRing<RNP, kPF2, 2> r2;
+  WGroupF8<1> wg1[4];  // NP == 8: lo8 + scales of a whole GEMM1 stage (K = 256 = 4 groups)
+  WGroupF8<2> wg2[2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, 2 n-tiles)
+  const size_t w2f8_nt = (size_t)(F / 64) * kF8Rec;
+  auto w1f8_lane = [&](int ft) { return w1f8 + (size_t)ft * 4 * kF8Rec + lane; };
+  auto w2f8_lane = [&](int c) { return w2f8 + ((size_t)(2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
+  auto fill1 = [&](int ft) {  // start the W1 stream of hidden tile ft
+    if constexpr (NP == 8) {
+      ring_fill_f8<kPF1, 1>(r1, w1f8_lane(ft), 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) f8_group_load<1>(wg1[g], w1f8_lane(ft) + (size_t)g * kF8Rec, 0);
+    } else {
+      ring_fill<RNP, kPF1, 1>(r1, w1p + (size_t)ft * (kD / 16) * 128 + lane, 0, kD / 16);
+    }
+  };
+  auto fill2 = [&](int c) {  // start the W2 stream of chunk c
+    if constexpr (NP == 8) {
+      ring_fill_f8<kPF2, 2>(r2, w2f8_lane(c), w2f8_nt);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(c) + (size_t)g * kF8Rec, w2f8_nt);
+    } else {
+      ring_fill<RNP, kPF2, 2>(r2, w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
+                             min(kFC / 16, ks2_total - c * (kFC / 16)));
+    }
+  };
   // both weight streams start before the LayerNorm prologue
   if (producer) {
-    if (wl < nft) ring_fill<NP, kPF1, 1>(r1, w1p + (size_t)wl * (kD / 16) * 128 + lane, 0, kD / 16);
+    if (wl < nft) fill1(wl);
   } else {
-    ring_fill<NP, kPF2, 2>(r2, w2p + (size_t)(2 * wl) * ks2_total * 128 + lane, w2_nt_stride, min(kFC / 16, ks2_total));
+    fill2(0);
   }
   rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b);
   TL_STAMP();  // 1: prologue done
@@ -126,7 +159,8 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
       const int mt = step >> 3, q = step & 7;
       const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
-      const hl2_t sp = ACT == 0 ? split2<NP>(silu_exp2(u0), silu_exp2(u1)) : split2<NP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
+      constexpr int SNP = NP == 1 ? 1 : 3;
+      const hl2_t sp = ACT == 0 ? split2<SNP>(silu_exp2(u0), silu_exp2(u1)) : split2<SNP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
       if ((q & 1) == 0) {
         keep_hi = sp.hi;
         keep_lo = sp.lo;
@@ -136,6 +170,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
         hi.xy = keep_hi, hi.zw = sp.hi, lo.xy = keep_lo, lo.zw = sp.lo;
         *(h4*)dst = hi;
         if (NP == 3) *(h4*)(dst + kHPlane) = lo;
+        if (NP == 8) {
+          const uint2 lb = __builtin_bit_cast(uint2, lo);
+          *(unsigned*)(hb + kHPlane + (mt * 32 + (lane & 31)) * kH8Ld + lo8_pos(wl * 32 + 4 * hh + (q >> 1) * 8)) =
+              __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+        }
       }
     };
     auto init_bias = [&](f32x16 (&acc)[2][1], int ft) {
@@ -161,15 +200,21 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
       if (do_gemm) {
         init_bias(cur, ft);
         const uint4* w1_lane = w1p + (size_t)ft * (kD / 16) * 128 + lane;
+        const char* a8_lane = smem + kAPlane + (lane & 31) * kA8Ld + hh * 32;
         if (do_silu) {
           auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
-          gemm_ring<NP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
-                                                                                  0, r1, side);
+          if constexpr (NP == 8)
+            gemm_ring_f8<4, 1, true, kPF1, decltype(side), 5>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(ft), 0, r1, wg1, side);
+          else
+            gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
+                                                                                     0, r1, side);
+        } else {
+          if constexpr (NP == 8)
+            gemm_ring_f8<4, 1, true, kPF1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(ft), 0, r1, wg1);
+          else
+            gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
         }
-        else
-          gemm_ring<NP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
-        if (ft + 4 < nft)  // next chunk's W1 stream
-          ring_fill<NP, kPF1, 1>(r1, w1p + (size_t)(ft + 4) * (kD / 16) * 128 + lane, 0, kD / 16);
+        if (ft + 4 < nft) fill1(ft + 4);  // next chunk's W1 stream
       } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
 #pragma unroll
         for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
@@ -192,13 +237,15 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
         const char* h_lane = lds_h + (c & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
         const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
         const uint4* w2_lane = w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
-        if (ks2 == kFC / 16)
-          gemm_ring<NP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
-        else
-          gemm_plain<NP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
-        if (c + 1 < nchunk)  // next chunk's W2 stream: in flight across the barrier
-          ring_fill<NP, kPF2, 2>(r2, w2_lane + (size_t)(kFC / 16) * 128, w2_nt_stride,
-                                 min(kFC / 16, ks2_total - (c + 1) * (kFC / 16)));
+        if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
+          const char* h8_lane = lds_h + (c & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
+          gemm_ring_f8<2, 2, false, kPF2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(c), w2f8_nt, r2, wg2);
+        } else if (ks2 == kFC / 16) {
+          gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+        } else {
+          gemm_plain<RNP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+        }
+        if (c + 1 < nchunk) fill2(c + 1);  // next chunk's W2 stream: in flight across the barrier
       }
       TL_STAMP();  // consumer: slot work done
       __syncthreads();
@@ -266,12 +313,18 @@ static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {
   }
   const int grid = (a.M + kTileRows - 1) / kTileRows;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), kFfnLds, st, a.x, a.M, a.res_scale, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
-                     a.b2, a.F, a.fin_g, a.fin_b);
+                     a.b2, a.F, a.fin_g, a.fin_b, a.w1f8, a.w2f8);
   return hipGetLastError();
 }
 
-hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st) {
+hipError_t launch_ffn(const FfnArgs& a, int np_in, hipStream_t st) {
+  int np = np_in;
   const bool fl = a.fin_g != nullptr;
+  if (np == 8 && (a.F % kFC != 0 || !a.w1f8 || !a.w2f8)) np = 3;  // the f8 stream needs whole 128-wide chunks
+  if (np == 8) {
+    if (a.relu) return fl ? launch_ffn_t<8, true, 1>(a, st) : launch_ffn_t<8, false, 1>(a, st);
+    return fl ? launch_ffn_t<8, true, 0>(a, st) : launch_ffn_t<8, false, 0>(a, st);
+  }
   if (a.relu) {
     if (np == 3) return fl ? launch_ffn_t<3, true, 1>(a, st) : launch_ffn_t<3, false, 1>(a, st);
     return fl ? launch_ffn_t<1, true, 1>(a, st) : launch_ffn_t<1, false, 1>(a, st);

@@ -30,6 +30,67 @@ hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float sca
   return hipGetLastError();
 }
 
+// "f8" stream for the fp16 + 2 x fp8-correction product (eec_device.h, NP == 8):
+// per (n-tile, 64-k group) a record of kF8Rec uint4 = [4 fp16 hi fragments][lo8: 32 e5m2 bytes per lane]
+// [E8M0 scale dword per lane].  lo = scale*W - fp16(scale*W) is quantised per 32-k block (two k-steps) to
+// e5m2 after division by 2^(floor(log2 max|lo|) - 14); lane r + 32 b carries the scale of block b of row r.
+__global__ void pack_frags_f8_kernel(const float* __restrict__ w, int N, int K, uint4* __restrict__ out, int total, float scale) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, rec = idx >> 6;
+  const int NG = K / 64;
+  const int nt = rec / NG, g = rec - nt * NG;
+  const int r = lane & 31, h = lane >> 5, n = nt * 32 + r;
+  uint4* o = out + (size_t)rec * kF8Rec;
+  float lo[32];  // this lane's 32 slots: slot p <-> k = 64g + 16(p/8) + 8h + p%8
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    h8 hi;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 64 * g + 16 * q + 8 * h + j;
+      const float v = (n < N) ? w[(size_t)n * K + k] * scale : 0.f;
+      hi[j] = to_half_sat(v);
+      lo[8 * q + j] = v - (float)hi[j];
+    }
+    o[q * 64 + lane] = __builtin_bit_cast(uint4, hi);
+  }
+  // block b = slots [16b, 16b+16) of BOTH lane halves = k in [64g + 32b, 64g + 32b + 32): recompute the other half's residuals
+  int ebias[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    float m = 0.f;
+    for (int kk = 0; kk < 32; ++kk) {
+      const int k = 64 * g + 32 * b + kk;
+      const float v = (n < N) ? w[(size_t)n * K + k] * scale : 0.f;
+      m = fmaxf(m, fabsf(v - (float)to_half_sat(v)));
+    }
+    int e = 0;
+    if (m > 0.f) e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127 - 14;  // scaled max lands in [2^14, 2^15)
+    ebias[b] = min(max(e + 127, 0), 254);
+  }
+  unsigned bytes[8];
+#pragma unroll
+  for (int d = 0; d < 8; ++d) bytes[d] = 0u;
+#pragma unroll
+  for (int p = 0; p < 32; ++p) {
+    const float v = ldexpf(lo[p], 127 - ebias[p >> 4]);
+    unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, (half_t)v);
+    hb = min((hb & 0x7fffu) + 0x80u, 0x7b00u) | (hb & 0x8000u);  // round to nearest on the dropped byte, clamp to e5m2 max
+    bytes[p >> 2] |= (hb >> 8) << (8 * (p & 3));
+  }
+  o[256 + 2 * lane] = make_uint4(bytes[0], bytes[1], bytes[2], bytes[3]);
+  o[256 + 2 * lane + 1] = make_uint4(bytes[4], bytes[5], bytes[6], bytes[7]);
+  ((int*)(o + 384))[lane] = ebias[h];  // lane r + 32 b supplies the scale of block b
+}
+
+hipError_t launch_pack_frags_f8(const float* w, int N, int K, uint4* out, float scale, hipStream_t st) {
+  if (K % 64) return hipErrorInvalidValue;
+  const int total = ((N + 31) / 32) * (K / 64) * 64;
+  hipLaunchKernelGGL(pack_frags_f8_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, K, out, total, scale);
+  return hipGetLastError();
+}
+
 // conv2 weight [co][ci][3] -> fragments of W'[co][k], k = j*cin + ci  (frame-major im2col order)
 __global__ void pack_conv_jci_kernel(const float* __restrict__ w, int cout, int cin, uint4* __restrict__ out, int total) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

@@ -53,7 +53,7 @@ class _HipEncoderMixin:
 
     _head_attr = "linears"
     _pe_attr = "positional_encoder"
-    precision = "f16x3"
+    precision = "f16f8"  # fastest operand mode that meets the 1e-3 log-prob tolerance
 
     def _hip_init(self, d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len):
         self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len,

@@ -30,7 +30,9 @@ extern "C" {
 enum {
   EEC_PREC_F16X3 = 0, /* hi/lo-split fp16, 3 MFMA passes per GEMM: |dlogp| ~2e-4, parity mode   */
   EEC_PREC_MIXED = 1, /* feed-forward GEMMs single-pass fp16, all others split: |dlogp| ~1e-3  */
-  EEC_PREC_F16 = 2    /* every GEMM single-pass fp16: |dlogp| ~3e-3                            */
+  EEC_PREC_F16 = 2,   /* every GEMM single-pass fp16: |dlogp| ~3e-3                            */
+  EEC_PREC_F16F8 = 3  /* as F16X3, but the feed-forward GEMMs compute the two hi/lo correction products
+                         with block-scaled fp8 (e5m2) MFMAs at twice the fp16 rate: |dlogp| ~3e-4 */
 };
 
 /* Constructor kwargs of Early_conformer that shape the encoder (early_exit.py:567-615;

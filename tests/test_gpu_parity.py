@@ -2,6 +2,7 @@
 nn.Module -> ctypes -> C-ABI, against the CPU oracle and the committed golden fixtures.
 
 Tolerances (max |delta log-prob| vs the fp32 reference path, stated per operand mode):
+    f16f8  1e-3   (default: as f16x3 with the feed-forward corrections in block-scaled fp8; measured ~3.3e-4)
     f16x3  1e-3   (north_star's tolerance; measured ~2.5e-4 on the 12-layer model)
     mixed  2.5e-3 (measured ~1.1e-3)
     f16    6e-3   (measured ~2.9e-3)
@@ -16,7 +17,7 @@ from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses, f
 from oracle import conformer_ref as R
 
 pytestmark = pytest.mark.gpu
-TOL = {"f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}
+TOL = {"f16f8": 1e-3, "f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}
 
 
 def make_pair(kw, seed, style="trained", head_scale=1.0):
@@ -28,7 +29,7 @@ def make_pair(kw, seed, style="trained", head_scale=1.0):
     return ref, gpu.cuda()
 
 
-def run_gpu(model, mel, lens, prec="f16x3"):
+def run_gpu(model, mel, lens, prec="f16f8"):
     model.precision = prec
     with torch.no_grad():
         out = model(mel.cuda(), lens)
@@ -43,7 +44,7 @@ def test_native_library_is_loaded():
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "mixed", "f16"])
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "mixed", "f16"])
 @pytest.mark.parametrize("name", ["small", "small_h4_k7", "config1"])
 def test_golden_logprobs(name, prec):
     """Committed fixtures made by the reference's own Early_conformer class body (make_golden.py)."""
@@ -71,7 +72,7 @@ def test_golden_greedy_decode_exact():
                                                head_scale=float(z["head_scale"])))
     gpu = gpu.cuda()
     mel = synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"]))
-    gpu.precision = "f16x3"
+    gpu.precision = "f16f8"
     with torch.no_grad():
         out = gpu(mel.cuda(), torch.from_numpy(z["lengths"]))
         got = gpu.greedy_decode(out)
@@ -107,7 +108,7 @@ def test_greedy_kernel_bit_exact_on_same_logprobs():
             assert tokens[i, : counts[i]].tolist() == R.greedy_ctc(lp[i])
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "f16"])
 def test_every_substep_against_oracle(prec):
     kw = base_kwargs(n_enc_exits=2, n_enc_layers=2, d_feed_forward=512)
     ref, gpu = make_pair(kw, seed=4)
@@ -120,7 +121,7 @@ def test_every_substep_against_oracle(prec):
             x = gpu._run_encoder(mel.cuda(), lens, want_out=False, stop_after=k, want_x=True)[2].cpu()
         scale = want.abs().max().item()
         err = (x - want).abs().max().item()
-        assert err < (2e-4 if prec == "f16x3" else 2e-3) * max(scale, 1.0), f"sub-step {k}: {err:.3e} (scale {scale:.2f})"
+        assert err < {"f16x3": 2e-4, "f16f8": 4e-4, "f16": 2e-3}[prec] * max(scale, 1.0), f"sub-step {k}: {err:.3e} (scale {scale:.2f})"
 
 
 @pytest.mark.parametrize("B,T,lens", [
@@ -138,7 +139,7 @@ def test_ragged_shapes(B, T, lens):
         want = ref(mel, lt)
     got = run_gpu(gpu, mel, lt)
     assert got.shape == want.shape
-    assert (got - want).abs().max().item() < TOL["f16x3"]
+    assert (got - want).abs().max().item() < TOL["f16f8"]
     assert torch.allclose(got.exp().sum(-1), torch.ones(got.shape[:-1]), atol=1e-4)
 
 
@@ -194,7 +195,7 @@ def test_exit_ctc_losses_match_torch_ctc(E, B, T, V, S):
     assert abs(got.sum().item() - R.summed_exit_ctc_loss(logp, tgt, tl).item()) < 1e-4 * max(1.0, want.sum().item())
 
 
-@pytest.mark.parametrize("prec", ["f16x3", "f16"])
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "f16"])
 def test_legacy_early_encoder_golden(prec):
     """the legacy pre-norm transformer encoder on the same kernels (attention without mask,
     ReLU feed-forward, group-final LayerNorm); fixture produced by the reference's own, unmodified Early_encoder."""

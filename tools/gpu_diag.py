@@ -29,7 +29,7 @@ m = Early_conformer(**kw).eval()
 m.load_state_dict(sd)
 m = m.cuda()
 names = ["stem"] + [f"L{i//4}.{['ffn1','attn','conv','ffn2'][i%4]}" for i in range(len(steps) - 1)]
-for prec in ("f16x3", "mixed", "f16"):
+for prec in ("f16f8", "f16x3", "mixed", "f16"):
     m.precision = prec
     print(f"== precision {prec}")
     with torch.no_grad():
@@ -42,7 +42,7 @@ for prec in ("f16x3", "mixed", "f16"):
     print(f"  log-probs: max|d| {d.max().item():.3e} mean {d.mean().item():.3e} per-exit {[f'{d[e].max().item():.2e}' for e in range(d.size(0))]}")
     print(f"  argmax mismatch frac {(got.argmax(-1) != want.argmax(-1)).float().mean().item():.2e}")
 torch.cuda.synchronize()
-for prec in ("f16x3", "f16"):
+for prec in ("f16f8", "f16x3", "f16"):
     m.precision = prec
     melc = mel.cuda()
     with torch.no_grad():
