@@ -491,10 +491,16 @@ __device__ __forceinline__ void layer_norm_rows(float4 (&v)[N], const float4 g, 
   }
 }
 
-template <int NP, bool DO_LN, int RPW = 16>
+struct NoPrefetch {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `after_loads()` runs once, right after the row loads have been issued and before their first use: the place
+// to start the weight streams.  (Loads return in order: a weight prefetch issued BEFORE the rows makes the
+// LayerNorm wait behind ~100 KiB of weight traffic.)
+template <int NP, bool DO_LN, int RPW = 16, typename After = NoPrefetch>
 __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* __restrict__ x, int row0, int M,
                                                    const float* __restrict__ gamma,
-                                                   const float* __restrict__ beta) {
+                                                   const float* __restrict__ beta, After after_loads = After()) {
   const int lane = lane_id(), w = wave_id();
   float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
   if (DO_LN) {
@@ -510,6 +516,10 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
       const int row = row0 + w * RPW + b0 + i;
       v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (row < M) v[i] = ((const float4*)(x + (size_t)row * kD))[lane];
+    }
+    if (b0 == 0) {
+      __builtin_amdgcn_sched_barrier(0);
+      after_loads();
     }
     if (DO_LN) layer_norm_rows<NB>(v, g, bt);
 #pragma unroll

@@ -138,13 +138,15 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
                              min(kFC / 16, ks2_total - c * (kFC / 16)));
     }
   };
-  // both weight streams start before the LayerNorm prologue
-  if (producer) {
-    if (wl < nft) fill1(wl);
-  } else {
-    fill2(0);
-  }
-  rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b);
+  // both weight streams start inside the LayerNorm prologue, right behind the x-row loads
+  auto start_streams = [&]() {
+    if (producer) {
+      if (wl < nft) fill1(wl);
+    } else {
+      fill2(0);
+    }
+  };
+  rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b, start_streams);
   TL_STAMP();  // 1: prologue done
   __syncthreads();
   TL_STAMP();  // 2: after prologue barrier
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
   // and written to H[c & 1] in slot c+1 -- inside the k-loop of GEMM1(c+1), two values per k-step in
   // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
   const int nslots = nchunk + 2;
+  f32x16 acc2c[2][2];  // consumers' [64 x 64] output accumulators (unused by producers)
   if (producer) {
     // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
     auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
       if (s + 1 < nslots) slot(s + 1, accB, accA);
     }
   } else {
-    f32x16 acc2[2][2];
+    f32x16 (&acc2)[2][2] = acc2c;
     zero_acc(acc2);
     for (int s = 0; s < nslots; ++s) {
       if (s >= 2) {
@@ -251,10 +254,19 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
       __syncthreads();
       TL_STAMP();  // consumer: barrier passed
     }
-    // the consumers hold the [64, 256] result: stage it through the fp32 tile (aliases the A planes;
-    // the last barrier above guarantees no producer still reads them)
-    acc_to_etile<2>(smem, acc2, wl * 64, b2);
   }
+  // residual rows of this wave: issued now, consumed after the tile exchange below
+  float4 xr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = row0 + w * 8 + i;
+    xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // the consumers hold the [64, 256] result: stage it through the fp32 tile (aliases the A planes;
+  // the last barrier of the loops guarantees no producer still reads them)
+  if (!producer) acc_to_etile<2>(smem, acc2c, wl * 64, b2);
   __syncthreads();
 
   float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -266,12 +278,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int rl = w * 8 + i, row = row0 + rl;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) v[i] = ((const float4*)(x + (size_t)row * kD))[lane];
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+      v[i] = xr[i];
       const float4 e = *(const float4*)(smem + (w * 8 + i) * kELd + lane * 16);
       v[i].x += res_scale * e.x;
       v[i].y += res_scale * e.y;

@@ -51,8 +51,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
   WRing<NP, kLPF> rq, rk;
-  ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, w), 0, kD / 16);
-  rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b);
+  rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b,
+                                  [&]() { ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, w), 0, kD / 16); });
   __syncthreads();
 
   // row -> (utterance, frame) of this lane's two frames
@@ -317,8 +317,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   const bool active = 32 * w < a.V;  // wave-uniform
   WRing<NP, kLPF> r;
-  if (active) ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
-  rows_f32_to_planes<NP, false, 8>(smem, a.x, row0, a.M, nullptr, nullptr);
+  rows_f32_to_planes<NP, false, 8>(smem, a.x, row0, a.M, nullptr, nullptr,
+                                   [&]() { if (active) ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16); });
   __syncthreads();
   f32x16 acc[2][1];
   if (active) {
