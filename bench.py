@@ -145,6 +145,22 @@ def main():
         d = time.perf_counter() - t1
         forward_only = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4)}
 
+    # HBM-side bytes per FFN launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
+    # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
+    # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
+    if roofline is not None and args.precision == "f16f8":
+        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_ffn_kernel_f16f8.txt")
+        if os.path.exists(pmc):
+            fetch, write = [], []
+            for ln in open(pmc):
+                if "ffn_kernel<8" in ln and "FETCH_SIZE" in ln:
+                    fetch.append(float(ln.split("avg/dispatch")[1].split()[0]))
+                if "ffn_kernel<8" in ln and "WRITE_SIZE" in ln:
+                    write.append(float(ln.split("avg/dispatch")[1].split()[0]))
+            if fetch and write:
+                roofline["traffic"] = round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0)
+                roofline["traffic_source"] = "profiles/r01_d_pmc_ffn_kernel_f16f8.txt (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)"
+
     # ---- the other operand modes (reported, never the headline) ----
     modes = {}
     if rank == 0 and world == 1 and not args.no_modes:
