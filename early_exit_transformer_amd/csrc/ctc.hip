@@ -10,8 +10,8 @@
 // lane arrive with that lane's exponent and both sides are brought to the larger one.  Dynamic range
 // ACROSS lanes is therefore unbounded -- necessary, because dead-end prefixes (e.g. "all blank so
 // far") can be 1e60 times more probable than the states that will reach the end -- while the
-// dependent chain per step is 3 DPP lane shifts, a few ldexp, 2 adds and 1 multiply.  The exp of the
-// emissions is computed kCtcAhead steps earlier, off the chain.
+// dependent chain per step is 3 DPP lane shifts, a few ldexp, 2 adds and 1 multiply.  The emission
+// log-probs are gathered kCtcAhead steps ahead (their exp is independent of the alpha chain).
 #include <limits.h>
 
 #include "eec_kernels.h"
@@ -47,6 +47,14 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
       skip_ok[i] = k > 0 && label[i] != (int)targets[(size_t)b * S + k - 1];
     }
   }
+  float livef[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) {
+    livef[i] = live[i] ? 1.f : 0.f;
+    // keep every label in a VGPR: a label the compiler can prove wave-uniform (the blanks) would turn
+    // its gather into s_load + s_waitcnt lgkmcnt(0), which serialises the prefetch ring
+    asm volatile("" : "+v"(label[i]));
+  }
   float alpha[P];
   int ex = kCtcEmpty;  // this lane's states are alpha[i] * 2^ex
 #pragma unroll
@@ -55,57 +63,59 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
     alpha[i] = (s < 2 && s < L) ? __expf(lp[label[i]]) : 0.f;
   }
   if (lane == 0) ex = 0;
-  // emission probabilities are gathered (and exponentiated) kCtcAhead steps ahead of their use
-  constexpr int kCtcAhead = 8;
+  // emission log-probs are gathered kCtcAhead steps ahead of their use (exponentiated when used)
+  constexpr int kCtcAhead = P <= 4 ? 16 : 8;
   float emit[kCtcAhead][P];
 #pragma unroll
   for (int d = 0; d < kCtcAhead; ++d)
 #pragma unroll
-    for (int i = 0; i < P; ++i) emit[d][i] = (1 + d < Tq) ? __expf(lp[(size_t)(1 + d) * V + label[i]]) : 0.f;
-  for (int t0 = 1; t0 < Tq; t0 += kCtcAhead) {
+    for (int i = 0; i < P; ++i) emit[d][i] = lp[(size_t)min(1 + d, Tq - 1) * V + label[i]];
+  // one time step, branch-free (selects only) so that the unrolled group below is a single basic
+  // block and the emission loads keep their kCtcAhead-step lead (s_waitcnt vmcnt(N), not vmcnt(0))
+  auto step = [&](const float (&em)[P], bool renorm) {
+    // the previous lane's last two states and its exponent (lane 0 receives 0 / its own exponent)
+    float up1 = EEC_DPP_F(0.f, alpha[P - 1], 0x138);  // wave_shr:1
+    float up2 = EEC_DPP_F(0.f, alpha[P - 2], 0x138);
+    const int ex_up = EEC_DPP_I(ex, ex, 0x138);
+    const int ec = max(ex, ex_up);  // common scale of this step
+    const int d_own = max(ex - ec, -200), d_up = max(ex_up - ec, -200);
+    up1 = ldexpf(up1, d_up);
+    up2 = ldexpf(up2, d_up);
+    float cur[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) cur[i] = ldexpf(alpha[i], d_own);
+    ex = ec;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+      const float p1 = i >= 1 ? cur[i - 1] : up1;
+      const float p2 = i >= 2 ? cur[i - 2] : (i == 1 ? up1 : up2);
+      // exp(em) * livef is independent of the alpha chain; states beyond 2*len+1 are zeroed by livef
+      alpha[i] = (cur[i] + p1 + (skip_ok[i] ? p2 : 0.f)) * (__expf(em[i]) * livef[i]);
+    }
+    if (renorm) {  // compile-time: renormalise this lane every second step
+      float m = alpha[0];
+#pragma unroll
+      for (int i = 1; i < P; ++i) m = fmaxf(m, alpha[i]);
+      const bool any = m > 0.f;
+      const int e = any ? (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127 : 0;
+#pragma unroll
+      for (int i = 0; i < P; ++i) alpha[i] = ldexpf(alpha[i], -e);
+      ex = any ? ex + e : kCtcEmpty;
+    }
+  };
+  int t0 = 1;
+  for (; t0 + kCtcAhead <= Tq; t0 += kCtcAhead) {  // full groups
 #pragma unroll
     for (int d = 0; d < kCtcAhead; ++d) {
-      const int t = t0 + d;
-      if (t < Tq) {  // wave-uniform
-        // the previous lane's last two states and its exponent (lane 0 receives 0 / its own exponent)
-        float up1 = EEC_DPP_F(0.f, alpha[P - 1], 0x138);  // wave_shr:1
-        float up2 = EEC_DPP_F(0.f, alpha[P - 2], 0x138);
-        const int ex_up = EEC_DPP_I(ex, ex, 0x138);
-        const int ec = max(ex, ex_up);  // common scale of this step
-        const int d_own = max(ex - ec, -200), d_up = max(ex_up - ec, -200);
-        up1 = ldexpf(up1, d_up);
-        up2 = ldexpf(up2, d_up);
-        float cur[P];
+      step(emit[d], (d & 1) != 0);
+      const int tn = min(t0 + d + kCtcAhead, Tq - 1);  // clamped: a harmless re-read near the end
 #pragma unroll
-        for (int i = 0; i < P; ++i) cur[i] = ldexpf(alpha[i], d_own);
-        ex = ec;
-#pragma unroll
-        for (int i = 0; i < P; ++i) {
-          const float p1 = i >= 1 ? cur[i - 1] : up1;
-          const float p2 = i >= 2 ? cur[i - 2] : (i == 1 ? up1 : up2);
-          alpha[i] = live[i] ? (cur[i] + p1 + (skip_ok[i] ? p2 : 0.f)) * emit[d][i] : 0.f;
-        }
-        if (d & 1) {  // renormalise this lane every second step
-          float m = alpha[0];
-#pragma unroll
-          for (int i = 1; i < P; ++i) m = fmaxf(m, alpha[i]);
-          if (m > 0.f) {
-            const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127;
-#pragma unroll
-            for (int i = 0; i < P; ++i) alpha[i] = ldexpf(alpha[i], -e);
-            ex += e;
-          } else {
-            ex = kCtcEmpty;
-          }
-        }
-        const int tn = t + kCtcAhead;
-        if (tn < Tq) {
-#pragma unroll
-          for (int i = 0; i < P; ++i) emit[d][i] = __expf(lp[(size_t)tn * V + label[i]]);
-        }
-      }
+      for (int i = 0; i < P; ++i) emit[d][i] = lp[(size_t)tn * V + label[i]];  // raw: exp at use
     }
   }
+#pragma unroll
+  for (int d = 0; d < kCtcAhead; ++d)  // ragged tail (wave-uniform guard); its emissions are already in the ring
+    if (t0 + d < Tq) step(emit[d], (d & 1) != 0);
   // p(target) = a[L-1] + a[L-2]: at most two lanes contribute, each with its own exponent
   float tail = 0.f;
 #pragma unroll
