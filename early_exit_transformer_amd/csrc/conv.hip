@@ -26,6 +26,7 @@ constexpr int kGLd = kD * 2;                                // 512 B per staged 
 constexpr int kDwLds = 2 * kAPlane + kGRows * kGLd + kDwTaps * kD * 4;  // 67584 + 48128 + 31744 = 147456
 constexpr int kDPF = 4;
 
+EEC_TL_DEFINE(dw)
 template <int NP>
 __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -35,6 +36,7 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
   const int row0 = blockIdx.x * kTileRows;
   const int M = a.M, Tq = d.Tq;
 
+  EEC_TL_STAMP(dw, 0);
   WRing<NP, kDPF, 1> r;
   const uint4* w_lane = a.wp + (size_t)w * (kD / 16) * 128 + lane;
   ring_fill<NP, kDPF, 1>(r, w_lane, 0, kD / 16);
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
     *(uint4*)(lds_g + rl * kGLd + c16 * 16) = v;
   }
   for (int p = threadIdx.x; p < kDwTaps * kD / 4; p += 512) ((float4*)lds_w)[p] = ((const float4*)d.wfold)[p];
+  EEC_TL_STAMP(dw, 1);
   __syncthreads();
+  EEC_TL_STAMP(dw, 2);
   {
     const int c = (threadIdx.x & 127) * 2, tg = threadIdx.x >> 7;  // 2 channels x frames [16 tg, 16 tg + 16)
     const int m0 = row0 + tg * kDwFrames;                           // first output row of this thread
@@ -59,10 +63,22 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
     float2 acc[kDwFrames];
 #pragma unroll
     for (int i = 0; i < kDwFrames; ++i) acc[i] = bias;
-    // window rows are flattened rows m0-15 .. m0+30; fast path when they all lie in one utterance
+    // window rows are flattened rows m0-15 .. m0+30.  When the 16 output frames lie in one utterance
+    // (always, if T' % 16 == 0) the "same"-padding zeros are applied ONCE to the window (rows of the
+    // neighbouring utterances, or outside [0, M)) and the tap loop stays branch-free; only a frame
+    // group that straddles two utterances needs the per-output validity test.
     const int first = m0 - kDwHalo, last = m0 + kDwFrames - 1 + kDwHalo;
-    const bool interior = first >= 0 && last < M && first / Tq == last / Tq;  // wave-uniform (tg is per wave pair)
-    if (interior) {
+    const int m_last = min(m0 + kDwFrames - 1, M - 1);
+    const int b0 = min(m0, M - 1) / Tq;
+    const bool one_utt = b0 == m_last / Tq;  // wave-uniform (tg is per wave pair)
+    if (one_utt) {
+      const bool interior = first >= b0 * Tq && last < (b0 + 1) * Tq;
+      if (!interior) {
+        const int klo = b0 * Tq - first, khi = (b0 + 1) * Tq - 1 - first;
+#pragma unroll
+        for (int k = 0; k < kDwWin; ++k)
+          if (k < klo || k > khi) win[k] = make_float2(0.f, 0.f);
+      }
 #pragma unroll
       for (int j = 0; j < kDwTaps; ++j) {
         const float2 wv = *(const float2*)(lds_w + j * kD + c);
@@ -102,7 +118,9 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
       if (NP == 3) *(h2*)(smem + kAPlane + rl * kALd + c * 2) = sp.lo;
     }
   }
+  EEC_TL_STAMP(dw, 3);
   __syncthreads();
+  EEC_TL_STAMP(dw, 4);
   f32x16 acc2[2][1];
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
@@ -117,6 +135,7 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
   }
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   gemm_ring<NP, kD / 16, 1, true, kDPF>(acc2, a_lane, kALd, kAPlane, w_lane, 0, r);
+  EEC_TL_STAMP(dw, 5);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
@@ -133,6 +152,7 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
       }
     }
   }
+  EEC_TL_STAMP(dw, 6);
 }
 
 hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st) {

@@ -57,15 +57,30 @@ constexpr int kETile = kTileRows * kELd;      // 66560 (aliases the two A planes
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// Wave-wide reductions on the DPP crossbar (no LDS traffic, unlike __shfl_xor = ds_bpermute): xor-1 / xor-2
+// inside each quad, half-row and row mirrors -> every lane of a 16-lane row holds the row total; row_bcast15
+// into rows 1,3 and row_bcast31 into rows 2,3 -> lane 63 holds the wave total, returned wave-uniform.
+#define EEC_DPP_ADD(v, ctrl, rmask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xf, false)))
+#define EEC_DPP_MAX(v, ctrl, rmask) \
+  fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (v)), __builtin_bit_cast(int, (v)), ctrl, rmask, 0xf, false)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = EEC_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  v = EEC_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  v = EEC_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+  v = EEC_DPP_ADD(v, 0x140, 0xf);  // row_mirror
+  v = EEC_DPP_ADD(v, 0x142, 0xa);  // row_bcast15 -> rows 1, 3
+  v = EEC_DPP_ADD(v, 0x143, 0xc);  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = EEC_DPP_MAX(v, 0xB1, 0xf);
+  v = EEC_DPP_MAX(v, 0x4E, 0xf);
+  v = EEC_DPP_MAX(v, 0x141, 0xf);
+  v = EEC_DPP_MAX(v, 0x140, 0xf);
+  v = EEC_DPP_MAX(v, 0x142, 0xa);
+  v = EEC_DPP_MAX(v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ half_t to_half_sat(float x) {
@@ -452,18 +467,23 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 // ---------------------------------------------------------------------------
 // x fp32 [M][256] -> (optional LayerNorm) -> hi/lo planes.
 // All RPW rows of a wave are loaded first and their reductions run as RPW independent,
-// interleaved shuffle chains (a chain is 6 dependent cross-lane steps of ~100+ cycles each;
-// run one row at a time the prologue costs ~18k cycles, interleaved ~4k).
+// interleaved DPP chains (6 dependent cross-lane adds per row, N rows in flight).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    float t[N];
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0xB1, 0xf);
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = __shfl_xor(v[i], o, 64);
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0x4E, 0xf);
 #pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += t[i];
-  }
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0x141, 0xf);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0x140, 0xf);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0x142, 0xa);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = EEC_DPP_ADD(v[i], 0x143, 0xc);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
 }
 
 // LayerNorm of N rows held as one float4 per lane per row (row = 256 columns over 64 lanes).
@@ -559,3 +579,24 @@ __device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2]
 }
 
 }  // namespace eec
+
+// Diagnostic phase timeline (tools/phase_timeline.py; -DEEC_TL builds only): s_memtime stamps of waves 0
+// and 7 of workgroups 0..7, read back through eec_tl_read_<NAME>().
+#ifdef EEC_TL
+#define EEC_TL_DEFINE(NAME)                                                                       \
+  __device__ unsigned long long g_tl_##NAME[8 * 2 * 16];                                          \
+  extern "C" int eec_tl_read_##NAME(unsigned long long* out) {                                    \
+    (void)hipDeviceSynchronize();                                                                 \
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_##NAME), sizeof(g_tl_##NAME));           \
+  }
+#define EEC_TL_STAMP(NAME, IDX)                                                                   \
+  do {                                                                                            \
+    const int w_ = (int)(threadIdx.x >> 6);                                                       \
+    if (blockIdx.x < 8 && (w_ == 0 || w_ == 7) && (threadIdx.x & 63) == 0)                        \
+      g_tl_##NAME[(blockIdx.x * 2 + (w_ == 7)) * 16 + (IDX)] = __builtin_amdgcn_s_memtime();      \
+  } while (0)
+#else
+#define EEC_TL_DEFINE(NAME)
+#define EEC_TL_STAMP(NAME, IDX)
+#endif
+

@@ -105,6 +105,15 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
   const int nft = F / 32;  // 32-wide hidden tiles
   const int nchunk = (nft + 3) / 4;
   const int ks2_total = F / 16;
+  // The hidden chunks are summed in a ROTATED order that differs between the workgroups of an XCD
+  // (blockIdx % 8 picks the XCD, blockIdx / 8 the slot within it): all 32 CUs of an XCD stream the
+  // same weights out of the same L2, and walking them in lockstep makes every CU ask the same L2
+  // channel for the same line at the same time.
+#ifndef EEC_FFN_ROT
+#define EEC_FFN_ROT 0
+#endif
+  const int rot = (EEC_FFN_ROT && (nft & 3) == 0) ? (int)((blockIdx.x >> 3) % (unsigned)nchunk) : 0;
+  auto phys = [&](int c) { const int p = c + rot; return p >= nchunk ? p - nchunk : p; };
   const size_t w2_nt_stride = (size_t)ks2_total * 128;
 
 #ifdef EEC_TIMELINE
@@ -141,9 +150,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
   // both weight streams start inside the LayerNorm prologue, right behind the x-row loads
   auto start_streams = [&]() {
     if (producer) {
-      if (wl < nft) fill1(wl);
+      if (wl < nft) fill1(phys(0) * 4 + wl);
     } else {
-      fill2(0);
+      fill2(phys(0));
     }
   };
   rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b, start_streams);
@@ -195,9 +204,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     };
     // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
     auto slot = [&](int s, f32x16 (&cur)[2][1], f32x16 (&prev)[2][1]) {
-      const int ft = s * 4 + wl;
+      const int ft = (s < nchunk ? phys(s) : s) * 4 + wl;  // s >= nchunk: no GEMM1 (ft is out of range)
       const bool do_gemm = s < nchunk && ft < nft;
-      const bool do_silu = s >= 1 && s - 1 < nchunk && ft - 4 < nft;
+      const bool do_silu = s >= 1 && s - 1 < nchunk && phys(s - 1) * 4 + wl < nft;
       char* hb_prev = lds_h + ((s - 1) & 1) * 2 * kHPlane;
       h2 khi, klo;
       if (do_gemm) {
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
           else
             gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
         }
-        if (ft + 4 < nft) fill1(ft + 4);  // next chunk's W1 stream
+        if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(phys(s + 1) * 4 + wl);  // next chunk's W1 stream
       } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
 #pragma unroll
         for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
@@ -236,19 +245,19 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
     zero_acc(acc2);
     for (int s = 0; s < nslots; ++s) {
       if (s >= 2) {
-        const int c = s - 2;
-        const char* h_lane = lds_h + (c & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
+        const int cl = s - 2, c = phys(cl);  // logical slot chunk (picks the H buffer) / physical hidden chunk
+        const char* h_lane = lds_h + (cl & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
         const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
         const uint4* w2_lane = w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
         if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
-          const char* h8_lane = lds_h + (c & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
+          const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
           gemm_ring_f8<2, 2, false, kPF2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(c), w2f8_nt, r2, wg2);
         } else if (ks2 == kFC / 16) {
           gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
         } else {
           gemm_plain<RNP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
         }
-        if (c + 1 < nchunk) fill2(c + 1);  // next chunk's W2 stream: in flight across the barrier
+        if (cl + 1 < nchunk) fill2(phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
       }
       TL_STAMP();  // consumer: slot work done
       __syncthreads();

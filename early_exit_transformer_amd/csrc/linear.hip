@@ -14,7 +14,10 @@ namespace eec {
 
 constexpr int kLinThreads = 512;
 constexpr int kLinLds = 2 * kAPlane;  // 67584: the activation planes only
-constexpr int kLPF = 4;
+#ifndef EEC_LPF
+#define EEC_LPF 4
+#endif
+constexpr int kLPF = EEC_LPF;  // weight fragments (1 KiB each per plane) a wave keeps in flight
 
 __device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-order of an accumulator-fed operand
   return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
@@ -41,6 +44,8 @@ __device__ __forceinline__ const uint4* wfrag_lane(const uint4* wp, int nt) {
   return wp + (size_t)nt * (kD / 16) * 128 + lane_id();
 }
 
+EEC_TL_DEFINE(qkv)
+EEC_TL_DEFINE(glu)
 // ---------------------------------------------------------------------------
 template <int NP>
 __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
@@ -51,9 +56,12 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
   WRing<NP, kLPF> rq, rk;
+  EEC_TL_STAMP(qkv, 0);
   rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b,
                                   [&]() { ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, w), 0, kD / 16); });
+  EEC_TL_STAMP(qkv, 1);
   __syncthreads();
+  EEC_TL_STAMP(qkv, 2);
 
   // row -> (utterance, frame) of this lane's two frames
   int rb[2], rt[2];
@@ -72,6 +80,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   ring_fill<NP, kLPF, 1>(rk, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
   acc_init_bias<2>(acc, a.bias + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rq);
+  EEC_TL_STAMP(qkv, 3);
   ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, 16 + w), 0, kD / 16);  // V weights, in flight during the K pass
   {
     const float scale = kLog2e * rsqrtf((float)dh);
@@ -89,8 +98,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
       }
   }
   // ---- K ----
+  EEC_TL_STAMP(qkv, 4);
   acc_init_bias<2>(acc, a.bias + kD + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rk);
+  EEC_TL_STAMP(qkv, 5);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     if (ok[mt]) {
@@ -104,8 +115,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
       }
     }
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
+  EEC_TL_STAMP(qkv, 6);
   acc_init_bias<2>(acc, a.bias + 2 * kD + n0);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), 0, rq);
+  EEC_TL_STAMP(qkv, 7);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     if (ok[mt]) {
@@ -115,6 +128,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[(size_t)(8 * g + j) * a.Tp] = to_half_sat(acc[mt][0][4 * g + j]);
     }
+  EEC_TL_STAMP(qkv, 8);
 }
 
 template <typename K>
@@ -228,12 +242,25 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   const int row0 = blockIdx.x * kTileRows;
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   WRing<NP, kLPF, 1> r, rv;
+  EEC_TL_STAMP(glu, 0);
   ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
   rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
+  // residual rows of this wave: requested now, consumed after the out-proj GEMM (their latency hides under it)
+  float4 xres[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = row0 + w * 8 + i;
+    xres[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < a.M) xres[i] = ((const float4*)(a.x + (size_t)row * kD))[lane];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  EEC_TL_STAMP(glu, 1);
   __syncthreads();
+  EEC_TL_STAMP(glu, 2);
   f32x16 acc[2][1];
   acc_init_bias<2>(acc, a.bias + 32 * w);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
+  EEC_TL_STAMP(glu, 3);
   ring_fill<NP, kLPF, 1>(rv, wfrag_lane(gl.wp, w), 0, kD / 16);  // GLU value weights: in flight during the exchange
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -242,15 +269,16 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
     for (int g = 0; g < 4; ++g)
       *(float4*)(dst + g * 32) = make_float4(acc[mt][0][4 * g], acc[mt][0][4 * g + 1], acc[mt][0][4 * g + 2], acc[mt][0][4 * g + 3]);
   }
+  EEC_TL_STAMP(glu, 4);
   __syncthreads();  // tile complete; every wave is done reading the O planes
+  EEC_TL_STAMP(glu, 5);
   {
     const float4 g = ((const float4*)gl.ln_g)[lane], bt = ((const float4*)gl.ln_b)[lane];
     float4 v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rl = w * 8 + i, row = row0 + rl;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < a.M) v[i] = ((const float4*)(a.x + (size_t)row * kD))[lane];
+      v[i] = xres[i];
       const float4 e = *(const float4*)(lds_e + rl * kELd + lane * 16);
       v[i].x += e.x, v[i].y += e.y, v[i].z += e.z, v[i].w += e.w;
       if (row < a.M) ((float4*)(a.x + (size_t)row * kD))[lane] = v[i];
@@ -267,14 +295,18 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
       if (NP == 3) *(h4*)(smem + kAPlane + rl * kALd + lane * 8) = lo;
     }
   }
+  EEC_TL_STAMP(glu, 6);
   __syncthreads();
+  EEC_TL_STAMP(glu, 7);
   WRing<NP, kLPF, 1> rg;
   ring_fill<NP, kLPF, 1>(rg, wfrag_lane(gl.wp, 8 + w), 0, kD / 16);
   f32x16 av[2][1], ag[2][1];
   acc_init_bias<2>(av, gl.bias + 32 * w);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(av, a_lane, kALd, kAPlane, wfrag_lane(gl.wp, w), 0, rv);
+  EEC_TL_STAMP(glu, 8);
   acc_init_bias<2>(ag, gl.bias + kD + 32 * w);
   gemm_ring<NP, kD / 16, 1, true, kLPF>(ag, a_lane, kALd, kAPlane, wfrag_lane(gl.wp, 8 + w), 0, rg);
+  EEC_TL_STAMP(glu, 9);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
@@ -292,6 +324,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
       }
     }
   }
+  EEC_TL_STAMP(glu, 10);
 }
 
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {

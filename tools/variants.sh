@@ -6,7 +6,7 @@ for v in "$@"; do
   python - <<PY
 import json
 try:
-    d=json.load(open("gpurun_out/var_$v.json")); print("$v", d["ms_per_step"], "ffn_us", d["roofline"]["avg_launch_us"], {k:v["ms_per_step"] for k,v in d["modes"].items()})
+    d=json.load(open("gpurun_out/var_$v.json")); print("$v", d["ms_per_step"], "fwd", d["forward_only"]["ms_per_step"], {k:v["avg_us"] for k,v in d["kernel_time"].items()})
 except Exception as e: print("$v failed", e)
 PY
 done
