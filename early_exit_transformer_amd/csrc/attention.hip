@@ -29,6 +29,7 @@ struct AttnLds {
   static constexpr int TOTAL = KBYTES + VBYTES;
 };
 
+EEC_TL_DEFINE(attn)
 template <int DH, int NP>
 __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
   using L = AttnLds<DH>;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
   const bool active = q0 < a.Tq;  // wave-uniform
   const int len = min(a.enc_len[b], a.Tq);
 
+  EEC_TL_STAMP(attn, 0);
   h8 qf[KSQ];
   if (active) {
     const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + r) * DH + 8 * hh;
@@ -62,24 +64,41 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
   const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
   for (int kc0 = 0; kc0 < len; kc0 += kKC) {
     if (kc0) __syncthreads();
-    // stage K rows [kc0, kc0+KC) and V^T columns of the same keys; zero beyond Tp
+    // stage K rows [kc0, kc0+KC) and V^T columns of the same keys; zero beyond Tp.  All global loads of
+    // the chunk are issued before the first LDS write (one memory round trip, not one per piece).
     {
       constexpr int KP = DH / 8;  // 16-byte pieces per K row
-      for (int p = threadIdx.x; p < kKC * KP; p += kThreads) {
-        const int row = p / KP, c = p % KP;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kc0 + row < a.Tp) v = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
-        *(uint4*)(lds_k + row * L::KLD + c * 16) = v;
-      }
       constexpr int VP = kKC / 8;
-      for (int p = threadIdx.x; p < DH * VP; p += kThreads) {
-        const int row = p / VP, c = p % VP;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (kc0 + c * 8 < a.Tp) v = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
-        *(uint4*)(lds_v + row * L::VLD + c * 16) = v;
+      constexpr int KIT = kKC * KP / kThreads, VIT = DH * VP / kThreads;
+      static_assert(kKC * KP % kThreads == 0 && DH * VP % kThreads == 0, "staging loops assume whole passes");
+      uint4 kv[KIT], vv[VIT];
+#pragma unroll
+      for (int it = 0; it < KIT; ++it) {
+        const int p = it * kThreads + threadIdx.x, row = p / KP, c = p % KP;
+        kv[it] = make_uint4(0, 0, 0, 0);
+        if (kc0 + row < a.Tp) kv[it] = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < VIT; ++it) {
+        const int p = it * kThreads + threadIdx.x, row = p / VP, c = p % VP;
+        vv[it] = make_uint4(0, 0, 0, 0);
+        if (kc0 + c * 8 < a.Tp) vv[it] = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int it = 0; it < KIT; ++it) {
+        const int p = it * kThreads + threadIdx.x, row = p / KP, c = p % KP;
+        *(uint4*)(lds_k + row * L::KLD + c * 16) = kv[it];
+      }
+#pragma unroll
+      for (int it = 0; it < VIT; ++it) {
+        const int p = it * kThreads + threadIdx.x, row = p / VP, c = p % VP;
+        *(uint4*)(lds_v + row * L::VLD + c * 16) = vv[it];
       }
     }
+    EEC_TL_STAMP(attn, 1);
     __syncthreads();
+    EEC_TL_STAMP(attn, 2);
     if (!active) continue;
     const int nkt = (min(len - kc0, kKC) + 31) / 32;
     // online softmax over blocks of KB = 4 key tiles (128 keys): the per-block overhead (cross-half
@@ -144,6 +163,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
       }
     }
   }
+  EEC_TL_STAMP(attn, 3);
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
@@ -162,6 +182,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
         if (NP == 3) *(h4*)(a.o_lo + rowoff + d) = lo;
       }
   }
+  EEC_TL_STAMP(attn, 4);
 }
 
 template <int DH, int NP>

@@ -40,13 +40,34 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
   WRing<NP, kDPF, 1> r;
   const uint4* w_lane = a.wp + (size_t)w * (kD / 16) * 128 + lane;
   ring_fill<NP, kDPF, 1>(r, w_lane, 0, kD / 16);
-  for (int p = threadIdx.x; p < kGRows * 32; p += 512) {
-    const int rl = p >> 5, c16 = p & 31, row = row0 - kDwHalo + rl;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row >= 0 && row < M) v = *(const uint4*)(d.g + (size_t)row * kD + c16 * 8);
-    *(uint4*)(lds_g + rl * kGLd + c16 * 16) = v;
+  {  // stage the 94 GLU rows and the 31 folded tap rows: every global load is issued before the first LDS write
+    constexpr int GIT = (kGRows * 32 + 511) / 512, WIT = (kDwTaps * kD / 4 + 511) / 512;
+    uint4 gv[GIT];
+    float4 wv[WIT];
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) {
+      const int p = it * 512 + threadIdx.x, rl = p >> 5, c16 = p & 31, row = row0 - kDwHalo + rl;
+      gv[it] = make_uint4(0, 0, 0, 0);
+      if (rl < kGRows && row >= 0 && row < M) gv[it] = *(const uint4*)(d.g + (size_t)row * kD + c16 * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int p = it * 512 + threadIdx.x;
+      wv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p < kDwTaps * kD / 4) wv[it] = ((const float4*)d.wfold)[p];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int it = 0; it < GIT; ++it) {
+      const int p = it * 512 + threadIdx.x, rl = p >> 5, c16 = p & 31;
+      if (rl < kGRows) *(uint4*)(lds_g + rl * kGLd + c16 * 16) = gv[it];
+    }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int p = it * 512 + threadIdx.x;
+      if (p < kDwTaps * kD / 4) ((float4*)lds_w)[p] = wv[it];
+    }
   }
-  for (int p = threadIdx.x; p < kDwTaps * kD / 4; p += 512) ((float4*)lds_w)[p] = ((const float4*)d.wfold)[p];
   EEC_TL_STAMP(dw, 1);
   __syncthreads();
   EEC_TL_STAMP(dw, 2);

@@ -352,6 +352,9 @@ struct WGroupF8 {      // lo8 + scale of ONE 64-k group for NT n-tiles
 template <int NT>
 __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __restrict__ rec_lane, size_t nt_stride) {
   // rec_lane = record base + lane
+#ifdef EEC_ABLATE_W
+  if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
+#endif
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const uint4* r = rec_lane + nt * nt_stride - lane_id();
@@ -380,11 +383,19 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int cur = s & 1, nxt = cur ^ 1, q = s & 3, g = s >> 2;
+#ifdef EEC_ABLATE_A
+    if (s == 0) {  // timing-only build: one LDS fragment read per stage
+#else
     if (s + 1 < KS) {
+#endif
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
     }
+#ifdef EEC_ABLATE_A
+    if (s == 0) {
+#else
     if (q == 0) {
+#endif
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const uint4 l0 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64);
@@ -404,7 +415,11 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
       for (int mt = 0; mt < 2; ++mt)
         acc[mt][nt] = SWAP ? mfma16(bh, ah[cur][mt], acc[mt][nt]) : mfma16(ah[cur][mt], bh, acc[mt][nt]);
     }
+#ifdef EEC_ABLATE_W
+    if (false) {
+#else
     if (s + PF < KS) {
+#endif
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = rec_lane[nt * nt_stride + hi_addr(s + PF)];
     }
@@ -444,6 +459,9 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
 // ring fill for the f8 stream: hi fragments of the first PF k-steps of a stage
 template <int PF, int NT>
 __device__ __forceinline__ void ring_fill_f8(WRing<1, PF, NT>& r, const uint4* __restrict__ rec_lane, size_t nt_stride) {
+#ifdef EEC_ABLATE_W
+  if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
+#endif
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
@@ -580,8 +598,8 @@ __device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2]
 
 }  // namespace eec
 
-// Diagnostic phase timeline (tools/phase_timeline.py; -DEEC_TL builds only): s_memtime stamps of waves 0
-// and 7 of workgroups 0..7, read back through eec_tl_read_<NAME>().
+// Diagnostic phase timeline (tools/phase_timeline.py; -DEEC_TL builds only): s_memtime stamps of the first
+// and last wave of workgroups 0..7, read back through eec_tl_read_<NAME>().
 #ifdef EEC_TL
 #define EEC_TL_DEFINE(NAME)                                                                       \
   __device__ unsigned long long g_tl_##NAME[8 * 2 * 16];                                          \
@@ -591,9 +609,10 @@ __device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2]
   }
 #define EEC_TL_STAMP(NAME, IDX)                                                                   \
   do {                                                                                            \
-    const int w_ = (int)(threadIdx.x >> 6);                                                       \
-    if (blockIdx.x < 8 && (w_ == 0 || w_ == 7) && (threadIdx.x & 63) == 0)                        \
-      g_tl_##NAME[(blockIdx.x * 2 + (w_ == 7)) * 16 + (IDX)] = __builtin_amdgcn_s_memtime();      \
+    const int w_ = (int)(threadIdx.x >> 6), wl_ = (int)(blockDim.x >> 6) - 1;                     \
+    const int b_ = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));         \
+    if (b_ < 8 && (w_ == 0 || w_ == wl_) && (threadIdx.x & 63) == 0)                              \
+      g_tl_##NAME[(b_ * 2 + (w_ == wl_)) * 16 + (IDX)] = __builtin_amdgcn_s_memtime();            \
   } while (0)
 #else
 #define EEC_TL_DEFINE(NAME)

@@ -151,21 +151,34 @@ hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st) {
 // ---------------------------------------------------------------------------
 // fp16 planes in global ([M][256] hi, [M][256] lo) -> LDS planes, 512 threads.
 template <int NP>
-__device__ __forceinline__ void rows_planes_to_lds512(char* lds_act, const half_t* __restrict__ hi,
-                                                      const half_t* __restrict__ lo, int row0, int M) {
-  const int t = threadIdx.x;
+struct PlaneRegs {
+  uint4 h[4], l[NP == 3 ? 4 : 1];
+};
+// issue: all global loads of the tile's pieces (64 rows x 32 sixteen-byte pieces, 4 per thread per plane);
+// commit: the LDS writes.  Split so that a caller can queue further loads (weight ring, residual rows) behind
+// them and so that no LDS write sits between two loads (one memory round trip for the tile, not four).
+template <int NP>
+__device__ __forceinline__ void planes_issue512(PlaneRegs<NP>& pr, const half_t* __restrict__ hi,
+                                                const half_t* __restrict__ lo, int row0, int M) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
-    const int piece = it * kLinThreads + t;  // 64 rows x 32 sixteen-byte pieces
-    const int rl = piece >> 5, c16 = piece & 31;
-    const int row = row0 + rl;
-    uint4 vh = make_uint4(0, 0, 0, 0), vl = make_uint4(0, 0, 0, 0);
+    const int piece = it * kLinThreads + threadIdx.x, rl = piece >> 5, c16 = piece & 31, row = row0 + rl;
+    pr.h[it] = make_uint4(0, 0, 0, 0);
+    if (NP == 3) pr.l[it] = make_uint4(0, 0, 0, 0);
     if (row < M) {
-      vh = *(const uint4*)(hi + (size_t)row * kD + c16 * 8);
-      if (NP == 3) vl = *(const uint4*)(lo + (size_t)row * kD + c16 * 8);
+      pr.h[it] = *(const uint4*)(hi + (size_t)row * kD + c16 * 8);
+      if (NP == 3) pr.l[it] = *(const uint4*)(lo + (size_t)row * kD + c16 * 8);
     }
-    *(uint4*)(lds_act + rl * kALd + c16 * 16) = vh;
-    if (NP == 3) *(uint4*)(lds_act + kAPlane + rl * kALd + c16 * 16) = vl;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int NP>
+__device__ __forceinline__ void planes_commit512(char* lds_act, const PlaneRegs<NP>& pr) {
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int piece = it * kLinThreads + threadIdx.x, rl = piece >> 5, c16 = piece & 31;
+    *(uint4*)(lds_act + rl * kALd + c16 * 16) = pr.h[it];
+    if (NP == 3) *(uint4*)(lds_act + kAPlane + rl * kALd + c16 * 16) = pr.l[it];
   }
 }
 
@@ -243,8 +256,9 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
   WRing<NP, kLPF, 1> r, rv;
   EEC_TL_STAMP(glu, 0);
+  PlaneRegs<NP> pr;
+  planes_issue512<NP>(pr, a.a_hi, a.a_lo, row0, a.M);  // needed first: queued ahead of the weight ring
   ring_fill<NP, kLPF, 1>(r, wfrag_lane(a.wp, w), 0, kD / 16);
-  rows_planes_to_lds512<NP>(smem, a.a_hi, a.a_lo, row0, a.M);
   // residual rows of this wave: requested now, consumed after the out-proj GEMM (their latency hides under it)
   float4 xres[8];
 #pragma unroll
@@ -254,6 +268,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
     if (row < a.M) xres[i] = ((const float4*)(a.x + (size_t)row * kD))[lane];
   }
   __builtin_amdgcn_sched_barrier(0);
+  planes_commit512<NP>(smem, pr);
   EEC_TL_STAMP(glu, 1);
   __syncthreads();
   EEC_TL_STAMP(glu, 2);

@@ -16,8 +16,10 @@ with torch.no_grad():
     torch.cuda.synchronize()
 names = {"qkv": ["prologue", "barrier", "Q gemm", "Q store+fill", "K gemm", "K store", "V gemm", "V store"],
          "glu": ["loads->lds", "barrier", "out-proj gemm", "tile write", "barrier", "resid+LN+planes", "barrier", "value gemm", "gate gemm", "GLU+store"],
+         "attn": ["stage K,V", "barrier", "QK/softmax/PV", "normalise+store"],
          "dw": ["stage g+taps", "barrier", "depthwise+SiLU", "barrier", "pw2 gemm", "residual rmw"]}
 for nm, ph in names.items():
+    if not hasattr(lib, 'eec_tl_read_' + nm): continue
     fn = getattr(lib, "eec_tl_read_" + nm)
     buf = (C.c_ulonglong * (8 * 2 * 16))()
     fn(buf)
@@ -26,4 +28,4 @@ for nm, ph in names.items():
     for blk in (0, 5):
         for wv in (0, 1):
             t = a[blk, wv, :len(ph) + 1]
-            print(f"  block {blk} wave {'07'[wv]}: total {t[-1]-t[0]:6d} | " + " ".join(f"{int(v):5d}" for v in np.diff(t)))
+            print(f"  block {blk} wave {'0L'[wv]}: total {t[-1]-t[0]:6d} | " + " ".join(f"{int(v):5d}" for v in np.diff(t)))
