@@ -13,7 +13,7 @@ work runs at every N (weak scaling); ``forward_only`` reports the encoder forwar
     python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
-  roofline     dominant kernel (fused feed-forward): algorithmic flop per launch / mean launch
+  roofline     dominant kernel (fused row-tile chain: conv tail + feed-forward stages + in_proj): algorithmic flop per launch / mean launch
                duration from HIP events on the launch stream, vs the 2.5 PFLOP/s dense 16-bit MFMA peak
   cpu_baseline the CPU oracle (oracle/conformer_ref.py, a port of the reference path) timed on
                this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
@@ -115,7 +115,7 @@ def main():
     value = world * B * T * args.steps / dt
     flop_fwd, Tq = flops_per_forward(B, T)
 
-    # ---- roofline of the dominant kernel (fused FFN), HIP events on the launch stream ----
+    # ---- roofline of the dominant kernel (the fused chain), HIP events on the launch stream ----
     roofline, kernel_ms = None, None
     if rank == 0:
         model.set_profiling(True)
@@ -123,14 +123,24 @@ def main():
         torch.cuda.synchronize()
         prof = model.read_profile()
         model.set_profiling(False)
-        ffn_ms, ffn_n = prof["ffn"]
+        # dominant kernel = the chain kernel: [depthwise + pointwise-2 ->] FFN stage(s) [-> in_proj] of one row tile
+        # (csrc/ffn.hip).  Algorithmic flop of everything the chain launches of ONE forward execute, divided by
+        # the launches of one forward (E*L + 1), against the mean launch duration measured with HIP events.
+        ch_ms, ch_n = prof["chain"]
+        if ch_n == 0:
+            raise SystemExit("bench.py: the library did not run the fused production plan (no chain-kernel launches)")
         M = B * Tq
-        ffn_flop = 4.0 * CFG["d_model"] * CFG["d_feed_forward"] * M
-        achieved = ffn_flop / (ffn_ms / ffn_n * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "ffn_kernel", "achieved": round(achieved, 2),
+        D, F, K = CFG["d_model"], CFG["d_feed_forward"], CFG["depthwise_kernel_size"]
+        n_layers = CFG["n_enc_exits"] * CFG["n_enc_layers"]
+        chain_flop_fwd = 2.0 * M * n_layers * (4 * D * F + 3 * D * D + D * D + K * D)
+        chain_flop = chain_flop_fwd / (n_layers + 1)
+        achieved = chain_flop / (ch_ms / ch_n * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "ffn_chain_kernel", "achieved": round(achieved, 2),
                     "peak": MFMA_PEAK_FLOPS / 1e12, "unit": "TFLOP/s", "frac": round(achieved * 1e12 / MFMA_PEAK_FLOPS, 4),
-                    "traffic": None, "avg_launch_us": round(ffn_ms / ffn_n * 1e3, 2), "launches": ffn_n,
-                    "flop_per_launch": ffn_flop}
+                    "traffic": None, "avg_launch_us": round(ch_ms / ch_n * 1e3, 2), "launches": ch_n,
+                    "flop_per_launch": chain_flop,
+                    "note": "mean over the chain launches of a forward: 1 x [ffn1 -> in_proj], (E*L-1) x [dw+pw2 -> ffn2 -> "
+                            "ffn1 -> in_proj], 1 x [dw+pw2 -> ffn2]"}
         tot = sum(v[0] for v in prof.values())
         kernel_ms = {k: {"share": round(v[0] / tot, 4), "avg_us": round(v[0] / max(v[1], 1) * 1e3, 2), "n": v[1]}
                      for k, v in prof.items()}
@@ -149,17 +159,18 @@ def main():
     # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
     # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
     if roofline is not None and args.precision == "f16f8":
-        pmc = os.path.join(ROOT, "profiles", "r01_d_pmc_ffn_kernel_f16f8.txt")
+        pmc = os.path.join(ROOT, "profiles", "r01_f_pmc_chain_kernel_f16f8.txt")
         if os.path.exists(pmc):
             fetch, write = [], []
             for ln in open(pmc):
-                if "ffn_kernel<8" in ln and "FETCH_SIZE" in ln:
+                if "ffn_chain_kernel<8, 0, 3, 3, 2>" in ln and "FETCH_SIZE" in ln:
                     fetch.append(float(ln.split("avg/dispatch")[1].split()[0]))
-                if "ffn_kernel<8" in ln and "WRITE_SIZE" in ln:
+                if "ffn_chain_kernel<8, 0, 3, 3, 2>" in ln and "WRITE_SIZE" in ln:
                     write.append(float(ln.split("avg/dispatch")[1].split()[0]))
             if fetch and write:
                 roofline["traffic"] = round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0)
-                roofline["traffic_source"] = "profiles/r01_d_pmc_ffn_kernel_f16f8.txt (2*FETCH_SIZE + WRITE_SIZE, KiB -> B)"
+                roofline["traffic_source"] = ("profiles/r01_f_pmc_chain_kernel_f16f8.txt (2*FETCH_SIZE + WRITE_SIZE, KiB -> B; the "
+                                              "two-stage variant = 11 of the 13 launches)")
 
     # ---- the other operand modes (reported, never the headline) ----
     modes = {}

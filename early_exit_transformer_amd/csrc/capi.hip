@@ -61,7 +61,7 @@ size_t f8_u4(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 63) / 64) * 
 
 }  // namespace
 
-enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, KC_DW_PW2, KC_HEAD, KC_COUNT };
+enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, KC_DW_PW2, KC_HEAD, KC_CHAIN, KC_COUNT };
 
 struct eec_encoder {
   eec_config cfg;
@@ -416,6 +416,62 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       }
       if (taps_opt)
         EEC_HIP(hipMemcpyAsync(taps_opt + (size_t)e * M * D, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
+    }
+    return finish_dbg();
+  }
+
+  if (stop_after < 0) {
+    // Production plan: 3 launches per layer.  Everything that is local to a 64-row tile runs in ONE chain
+    // kernel per layer boundary:
+    //   [depthwise + pointwise-2 of layer l] -> ffn2(l) + final LN (+ exit tap) -> ffn1(l+1) -> in_proj(l+1)
+    // and only the two steps with cross-tile dependencies keep their own launch: attention (all keys of the
+    // utterance) and out_proj + LN + pointwise-1 + GLU (whose output the depthwise conv reads with a +-15 frame
+    // halo).  The sub-step hook (stop_after >= 0) uses the unfused plan below; both are parity-tested.
+    const int n_layers = c.n_exits * c.layers_per_exit;
+    auto qkv_args = [&](const PackedLayer& L) {
+      return QkvArgs{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+    };
+    auto stage1 = [&](const PackedLayer& L) {
+      return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
+                      L.ffn1_w1f8, L.ffn1_w2f8, 0.5f, nullptr};
+    };
+    auto stage2 = [&](const PackedLayer& L, float* tap) {
+      return FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
+                      L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap};
+    };
+    float* y_scratch = (float*)ws.mid_hi;  // exit rows for the head when no tap buffer is given (the stem scratch is dead)
+    {
+      ChainArgs ca{};
+      ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
+      ca.st[0] = stage1(enc->layers[0]);
+      ca.qkv = qkv_args(enc->layers[0]);
+      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, false, true, false, st));
+    }
+    for (int li = 0; li < n_layers; ++li) {
+      const PackedLayer& L = enc->layers[li];
+      const int e = li / c.layers_per_exit;
+      const bool exit_layer = (li + 1) % c.layers_per_exit == 0, last = li + 1 == n_layers;
+      AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+      TIMED(KC_ATTN, launch_attention(at, np_o, st));
+      ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+      GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
+      TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
+      float* tap = nullptr;  // where the exit's encoder output goes besides x (x itself moves on to ffn1 of the next layer)
+      if (exit_layer) tap = taps_opt ? taps_opt + (size_t)e * M * D : ((out && !last) ? y_scratch : nullptr);
+      ChainArgs ca{};
+      ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
+      ca.dw = DwArgs{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
+      ca.pw2 = ProjResArgs{ws.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+      ca.st[0] = stage2(L, tap);
+      if (!last) {
+        ca.st[1] = stage1(enc->layers[li + 1]);
+        ca.qkv = qkv_args(enc->layers[li + 1]);
+      }
+      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, true, !last, false, st));
+      if (exit_layer && out) {
+        HeadArgs h{last ? ws.x : tap, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+        TIMED(KC_HEAD, launch_head(h, np_o, st));
+      }
     }
     return finish_dbg();
   }

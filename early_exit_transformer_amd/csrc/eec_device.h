@@ -368,10 +368,13 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 // (row l%32, half l/32); rec_lane: first record (+lane); consecutive groups are kF8Rec uint4 apart.
 // hi fragments run through the register ring `r` (PF k-steps ahead, as gemm_ring); the lo8/scale blocks of
 // the whole stage are in `wg` (loaded by the caller one stage ahead).
-template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0>
+// NW: number of lo8 group buffers.  NW == NG: the whole stage is resident (loaded by the caller one stage ahead);
+// NW < NG: rolling buffers, group g lives in wg[g % NW] and is refilled with group g + NW right after its use
+// (the caller preloads groups 0 .. NW-1 of the next stage).
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG>
 __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
                                              int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
-                                             WRing<1, PF, NT>& r, const WGroupF8<NT> (&wg)[NG], Side side = Side()) {
+                                             WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side()) {
   constexpr int KS = 4 * NG;
   auto hi_addr = [&](int s) { return (size_t)(s >> 2) * kF8Rec + (size_t)(s & 3) * 64; };
   h8 ah[2][2];
@@ -428,21 +431,23 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
       for (int nt = 0; nt < NT; ++nt) {
         const i32x8 whi = {(int)w8[nt][0].x, (int)w8[nt][0].y, (int)w8[nt][1].x, (int)w8[nt][1].y,
                            (int)w8[nt][2].x, (int)w8[nt][2].y, (int)w8[nt][3].x, (int)w8[nt][3].y};
-        const i32x8 wlo = {(int)wg[g].lo[nt][0].x, (int)wg[g].lo[nt][0].y, (int)wg[g].lo[nt][0].z, (int)wg[g].lo[nt][0].w,
-                           (int)wg[g].lo[nt][1].x, (int)wg[g].lo[nt][1].y, (int)wg[g].lo[nt][1].z, (int)wg[g].lo[nt][1].w};
+        const WGroupF8<NT>& G = wg[g % NW];
+        const i32x8 wlo = {(int)G.lo[nt][0].x, (int)G.lo[nt][0].y, (int)G.lo[nt][0].z, (int)G.lo[nt][0].w,
+                           (int)G.lo[nt][1].x, (int)G.lo[nt][1].y, (int)G.lo[nt][1].z, (int)G.lo[nt][1].w};
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const i32x8 ahi = {(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
                              (int)a8[mt][2].x, (int)a8[mt][2].y, (int)a8[mt][3].x, (int)a8[mt][3].y};
           if (SWAP) {
             acc[mt][nt] = mfma_f8(whi, alo[mt], acc[mt][nt], kE8M0One, kE8M0One);
-            acc[mt][nt] = mfma_f8(wlo, ahi, acc[mt][nt], wg[g].sc[nt], kE8M0One);
+            acc[mt][nt] = mfma_f8(wlo, ahi, acc[mt][nt], G.sc[nt], kE8M0One);
           } else {
             acc[mt][nt] = mfma_f8(alo[mt], whi, acc[mt][nt], kE8M0One, kE8M0One);
-            acc[mt][nt] = mfma_f8(ahi, wlo, acc[mt][nt], kE8M0One, wg[g].sc[nt]);
+            acc[mt][nt] = mfma_f8(ahi, wlo, acc[mt][nt], kE8M0One, G.sc[nt]);
           }
         }
       }
+      if (NW < NG && g + NW < NG) f8_group_load<NT>(wg[g % NW], rec_lane + (size_t)(g + NW) * kF8Rec, nt_stride);
     }
     side(s);
     if (SIDE_VALU > 0) {
@@ -529,6 +534,28 @@ __device__ __forceinline__ void layer_norm_rows(float4 (&v)[N], const float4 g, 
   }
 }
 
+// N rows held as one float4 per lane per row (local rows rl0 .. rl0+N-1 of the tile) -> activation planes:
+// fp16 hi plane, plus the fp16 lo plane (NP == 3) or the permuted e5m2 lo byte plane (NP == 8).
+// Rows at or beyond M are written as zeros when zero_tail is set (a LayerNorm turns a zero row into beta).
+template <int NP, int N>
+__device__ __forceinline__ void rows_to_planes(char* lds_act, float4 (&v)[N], int rl0, int row0, int M, bool zero_tail) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const int rl = rl0 + i;
+    if (zero_tail && row0 + rl >= M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(v[i].x, v[i].y), s1 = split2<(NP == 1 ? 1 : 3)>(v[i].z, v[i].w);
+    h4 hi, lo;
+    hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+    *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
+    if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
+    if (NP == 8) {  // e5m2 bytes of the lo halves, permuted to the MX slot order
+      const uint2 lb = __builtin_bit_cast(uint2, lo);
+      *(unsigned*)(lds_act + kAPlane + rl * kA8Ld + lo8_pos(lane * 4)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+    }
+  }
+}
+
 struct NoPrefetch {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -560,20 +587,7 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
       after_loads();
     }
     if (DO_LN) layer_norm_rows<NB>(v, g, bt);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int rl = w * RPW + b0 + i;
-      if (DO_LN && row0 + rl >= M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(v[i].x, v[i].y), s1 = split2<(NP == 1 ? 1 : 3)>(v[i].z, v[i].w);
-      h4 hi, lo;
-      hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
-      *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
-      if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
-      if (NP == 8) {  // e5m2 bytes of the lo halves, permuted to the MX slot order
-        const uint2 lb = __builtin_bit_cast(uint2, lo);
-        *(unsigned*)(lds_act + kAPlane + rl * kA8Ld + lo8_pos(lane * 4)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
-      }
-    }
+    rows_to_planes<NP, NB>(lds_act, v, w * RPW + b0, row0, M, DO_LN);
   }
 }
 

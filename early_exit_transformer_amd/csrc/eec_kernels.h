@@ -19,6 +19,10 @@ struct FfnArgs {
 };
 hipError_t launch_ffn(const FfnArgs& a, int np, hipStream_t st);
 
+struct QkvArgs;
+struct DwArgs;
+struct ProjResArgs;
+
 struct QkvArgs {
   const float* x;  // [M][256]
   int M, B, Tq, Tp, H;  // Tq = T' (frames per utterance), Tp = padded to 32
@@ -75,6 +79,28 @@ struct DwArgs {
 };
 // fused depthwise conv + BN + SiLU -> pointwise-2 + residual (o_hi/o_lo of DwArgs are unused)
 hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st);
+
+// Chain kernel (ffn.hip): [depthwise + pointwise-2 front ->] 1 or 2 FFN stages [-> QKV tail] on one row tile.
+struct FfnStage {
+  const float *ln_g, *ln_b;
+  const uint4* w1p;
+  const float* b1;
+  const uint4* w2p;
+  const float* b2;
+  const float *fin_g, *fin_b;  // optional LayerNorm after the residual (layer-final / group-final)
+  const uint4 *w1f8, *w2f8;    // NP == 8 stream layout of the same matrices (optional)
+  float res_scale;
+  float* tap;                  // optional [M][256]: the stage's output rows are stored here too (exit taps)
+};
+struct ChainArgs {
+  float* x;  // [M][256] residual stream, updated in place
+  int M, F, nstage;
+  FfnStage st[2];
+  QkvArgs qkv;      // tail (x / M of this block are ignored)
+  DwArgs dw;        // front
+  ProjResArgs pw2;  // front (a_hi / a_lo unused)
+};
+hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_o, bool front, bool tail, bool relu, hipStream_t st);
 
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]

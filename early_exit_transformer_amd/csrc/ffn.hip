@@ -23,7 +23,7 @@
 // Algorithmic work: 4*D*F flop per row (2.097 MFLOP at D=256, F=2048); bound: MFMA.
 // Executed MFMA work is NP x that.  HBM/L2 traffic per launch: x read+write 2 KiB/row; each
 // workgroup streams all 2*D*F*2 B (x2 planes when NP=3) of weights once from L2.
-#include "eec_kernels.h"
+#include "eec_blocks.h"
 
 namespace eec {
 
@@ -48,19 +48,29 @@ template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF
 #define EEC_PF2_NP8 3
 #endif
 template <> struct FfnPf<8> { static constexpr int P1 = EEC_PF1_NP8, P2 = EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+#ifndef EEC_NW1
+#define EEC_NW1 4
+#endif
+constexpr int kNW1 = EEC_NW1;  // lo8 group buffers of the producers' GEMM1 (4 = whole stage resident)
 constexpr int kH8Ld = kFC + 16;  // 144: H lo8 byte plane row stride (NP == 8)
 
 #ifdef EEC_TIMELINE
 // Diagnostic build only: s_memtime stamps of wave 0 (producer) and wave 4 (consumer) of the first
-// 8 workgroups, written to a buffer nothing else reads.  Layout: [block][role][stamp], 64 stamps.
+// 8 workgroups, written to a buffer nothing else reads.  Layout: [block][role][stamp], 128 stamps.
 __device__ unsigned long long* g_timeline = nullptr;
 __device__ __forceinline__ void tl_stamp(int& idx) {
   const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0 && (w == 0 || w == 4) && blockIdx.x < 8 && g_timeline && idx < 64)
-    g_timeline[(blockIdx.x * 2 + (w >> 2)) * 64 + idx] = __builtin_amdgcn_s_memtime();
+  if ((threadIdx.x & 63) == 0 && (w == 0 || w == 4) && blockIdx.x < 8 && g_timeline && idx < 128)
+    g_timeline[(blockIdx.x * 2 + (w >> 2)) * 128 + idx] = __builtin_amdgcn_s_memtime();
   ++idx;
 }
-#define TL_STAMP() tl_stamp(tl_idx)
+#ifndef EEC_TL_NS
+#define EEC_TL_NS 0  // 0: stamp every launch; 1 / 2: only the variants with that many stages
+#endif
+#define TL_STAMP()                                  \
+  do {                                              \
+    if (EEC_TL_NS == 0 || EEC_TL_NS == NS) tl_stamp(tl_idx); \
+  } while (0)
 #ifdef EEC_KSTEP_STAMPS
 __device__ int g_ks_idx;  // stamps of consumer wave 0, block 0 only, slots 3..5
 __device__ unsigned long long g_ks[256];
@@ -79,36 +89,106 @@ extern "C" int eec_debug_ksteps(unsigned long long* out) {
 #define TL_STAMP()
 #endif
 
-// ACT 0: SiLU in the exp2 domain (Conformer; log2 e folded into the packed weights); ACT 1: ReLU (the
-// legacy pre-norm transformer layer, models/layers/position_wise_feed_forward.py:9-23, plain weights).
-template <int NP, bool FINAL_LN, int ACT>
-__global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__ x, int M, float res_scale,
-                                                             const float* __restrict__ ln_g,
-                                                             const float* __restrict__ ln_b,
-                                                             const uint4* __restrict__ w1p,
-                                                             const float* __restrict__ b1s,
-                                                             const uint4* __restrict__ w2p,
-                                                             const float* __restrict__ b2, int F,
-                                                             const float* __restrict__ fin_g,
-                                                             const float* __restrict__ fin_b,
-                                                             const uint4* __restrict__ w1f8,
-                                                             const uint4* __restrict__ w2f8) {
+// L2 warm-up: one dword per 128-byte line, lane l -> line first_line + l of [base, base + 128 * n_lines).
+// The value only feeds a sink that keeps the load alive.
+__device__ __forceinline__ unsigned touch_lines(const void* base, size_t first_line, size_t n_lines) {
+  const size_t ln = first_line + lane_id();
+  return ln < n_lines ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
+}
+// instruction j (0 or 1) of this wave's part of the workgroup's 1/32 share of an array (the workgroups of an
+// XCD -- blockIdx % 8 -- share one L2; a share is at most 2 x 64 lines per wave for the matrices used here)
+__device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, int wl, int j) {
+  const size_t n_lines = bytes / 128, per_wg = (n_lines + 31) / 32, per_wave = (per_wg + 3) / 4;
+  const size_t k = (size_t)j * 64 + lane_id();
+  const size_t ln = ((blockIdx.x >> 3) & 31) * per_wg + wl * per_wave + k;
+  return (k < per_wave && ln < n_lines) ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
+}
+template <int I>
+struct IntTag {
+  static constexpr int value = I;
+};
+// f(IntTag<0>{}), ..., f(IntTag<N-1>{}) for N <= 2: a stage loop whose index is a compile-time constant
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_assert(N >= 1 && N <= 2, "one or two stages");
+  f(IntTag<0>{});
+  if constexpr (N == 2) f(IntTag<1>{});
+}
+template <bool B>
+struct BoolTag {
+  static constexpr bool value = B;
+};
+// One FFN stage's packed weight streams.
+struct WPtrs {
+  const uint4 *w1p, *w2p, *w1f8, *w2f8;
+};
+
+// Row pass between two GEMM stages of the chain: the fp32 exchange tile `lds_e` (this stage's product, bias
+// included) is scaled and - HAS_RES - added to the residual rows `xr` (wave w owns local rows 8w .. 8w+7, one float4 per lane), the
+// optional final LayerNorm is applied, the rows are stored to x (and to `tap`), and - NPN != 0 - the rows are
+// LayerNormed with (nln_g, nln_b) and written as the NEXT stage's activation planes (NPN format) at `smem`.
+template <int NPN, bool HAS_RES>
+__device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, float* __restrict__ x, float4 (&xr)[8],
+                                              int row0, int M, float scale, const float* __restrict__ fin_g,
+                                              const float* __restrict__ fin_b, float* __restrict__ tap,
+                                              const float* __restrict__ nln_g, const float* __restrict__ nln_b) {
+  const int lane = lane_id(), w = wave_id();
+  float4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float4 e = *(const float4*)(lds_e + (w * 8 + i) * kELd + lane * 16);
+    v[i] = HAS_RES ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // !HAS_RES: the residual went in as the accumulator init
+    v[i].x += scale * e.x;
+    v[i].y += scale * e.y;
+    v[i].z += scale * e.z;
+    v[i].w += scale * e.w;
+  }
+  if (fin_g) layer_norm_rows<8>(v, ((const float4*)fin_g)[lane], ((const float4*)fin_b)[lane]);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int row = row0 + w * 8 + i;
+    if (row < M) {
+      ((float4*)(x + (size_t)row * kD))[lane] = v[i];
+      if (tap) ((float4*)(tap + (size_t)row * kD))[lane] = v[i];
+    }
+  }
+  if constexpr (NPN != 0) {
+    layer_norm_rows<8>(v, ((const float4*)nln_g)[lane], ((const float4*)nln_b)[lane]);
+    rows_to_planes<NPN, 8>(smem, v, w * 8, row0, M, true);
+  }
+}
+
+// The chain kernel: [conv-module tail ->] FFN stage(s) [-> QKV], one 64-row tile per workgroup, x rows touched
+// in HBM only for the residual stream.
+//   NP   FFN product format (1, 3, 8);  ACT 0: SiLU in the exp2 domain (Conformer; log2 e folded into the packed
+//        weights), 1: ReLU (legacy pre-norm layer, models/layers/position_wise_feed_forward.py:9-23, plain weights)
+//   FNP  0: stage 0 reads x;  else: the depthwise + pointwise-2 front (format FNP) produces x first
+//   QNP  0: none;  else: the attention in_proj of the NEXT half-layer (format QNP) runs on the final rows
+//   NS   number of FFN stages (1 or 2)
+template <int NP, int ACT, int FNP, int QNP, int NS>
+__global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kPF1 = FfnPf<NP>::P1, kPF2 = FfnPf<NP>::P2;
   const int lane = lane_id(), w = wave_id();
   const int hh = lane >> 5, wl = w & 3;
-  const bool producer = w >= 4;  // wave-uniform; consumers are the OLDER waves (issue arbitration: priority, then age)
+  const bool is_producer = w >= 4;  // wave-uniform; consumers are the OLDER waves (issue arbitration: priority, then age)
   const int row0 = blockIdx.x * kTileRows;
+  const int M = a.M, F = a.F;
+  float* __restrict__ x = a.x;
   char* lds_h = smem + 2 * kAPlane;  // H[buf][plane][64][136]
+  char* lds_e = lds_h;               // fp32 exchange tile: aliases the H buffers (dead outside the chunk loops), not the planes
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
   const int nft = F / 32;  // 32-wide hidden tiles
   const int nchunk = (nft + 3) / 4;
   const int ks2_total = F / 16;
-  // The hidden chunks are summed in a ROTATED order that differs between the workgroups of an XCD
-  // (blockIdx % 8 picks the XCD, blockIdx / 8 the slot within it): all 32 CUs of an XCD stream the
-  // same weights out of the same L2, and walking them in lockstep makes every CU ask the same L2
-  // channel for the same line at the same time.
+  // The hidden chunks can be summed in a ROTATED order that differs between the workgroups of an XCD (all 32
+  // CUs of an XCD stream the same weights out of the same L2 in lockstep): -4 % FFN time, but the fp32
+  // summation order then depends on the tile index, i.e. on an utterance's position in the batch.  Off by
+  // default: results are bit-identical under batch sharding.
+#ifndef EEC_WARM_SLOTS
+#define EEC_WARM_SLOTS 4  // slots before the end of a stage at which the consumers start the L2 warm-up
+#endif
 #ifndef EEC_FFN_ROT
 #define EEC_FFN_ROT 0
 #endif
@@ -121,195 +201,286 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_kernel(float* __restrict__
 #endif
   TL_STAMP();  // 0: kernel entry
   constexpr int RNP = NP == 8 ? 1 : NP;  // the f8 stream keeps only the hi fragments in the ring
+  // Everything below is instantiated ONCE PER ROLE (the tag is a compile-time bool) and the role split is the
+  // outermost branch: each role then carries only its own rings and accumulators through the stage loop
+  // (with the split inside the loop the register allocator keeps both roles' state live: ~600 spilled VGPRs).
+  auto run = [&](auto prod_tag) {
+  constexpr bool producer = decltype(prod_tag)::value;
   WRing<RNP, kPF1, 1> r1;
   WRing<RNP, kPF2, 2> r2;
-  WGroupF8<1> wg1[4];  // NP == 8: lo8 + scales of a whole GEMM1 stage (K = 256 = 4 groups)
+  WGroupF8<1> wg1[kNW1];  // NP == 8: lo8 + scales of GEMM1 (K = 256 = 4 groups), rolling through kNW1 buffers
   WGroupF8<2> wg2[2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, 2 n-tiles)
   const size_t w2f8_nt = (size_t)(F / 64) * kF8Rec;
-  auto w1f8_lane = [&](int ft) { return w1f8 + (size_t)ft * 4 * kF8Rec + lane; };
-  auto w2f8_lane = [&](int c) { return w2f8 + ((size_t)(2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
-  auto fill1 = [&](int ft) {  // start the W1 stream of hidden tile ft
+  auto w1f8_lane = [&](const WPtrs& W, int ft) { return W.w1f8 + (size_t)ft * 4 * kF8Rec + lane; };
+  auto w2f8_lane = [&](const WPtrs& W, int c) { return W.w2f8 + ((size_t)(2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
+  auto fill1 = [&](const WPtrs& W, int ft) {  // start the W1 stream of hidden tile ft
     if constexpr (NP == 8) {
-      ring_fill_f8<kPF1, 1>(r1, w1f8_lane(ft), 0);
+      ring_fill_f8<kPF1, 1>(r1, w1f8_lane(W, ft), 0);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) f8_group_load<1>(wg1[g], w1f8_lane(ft) + (size_t)g * kF8Rec, 0);
+      for (int g = 0; g < kNW1; ++g) f8_group_load<1>(wg1[g], w1f8_lane(W, ft) + (size_t)g * kF8Rec, 0);
     } else {
-      ring_fill<RNP, kPF1, 1>(r1, w1p + (size_t)ft * (kD / 16) * 128 + lane, 0, kD / 16);
+      ring_fill<RNP, kPF1, 1>(r1, W.w1p + (size_t)ft * (kD / 16) * 128 + lane, 0, kD / 16);
     }
   };
-  auto fill2 = [&](int c) {  // start the W2 stream of chunk c
+  auto fill2 = [&](const WPtrs& W, int c) {  // start the W2 stream of chunk c
     if constexpr (NP == 8) {
-      ring_fill_f8<kPF2, 2>(r2, w2f8_lane(c), w2f8_nt);
+      ring_fill_f8<kPF2, 2>(r2, w2f8_lane(W, c), w2f8_nt);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(c) + (size_t)g * kF8Rec, w2f8_nt);
+      for (int g = 0; g < 2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
     } else {
-      ring_fill<RNP, kPF2, 2>(r2, w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
+      ring_fill<RNP, kPF2, 2>(r2, W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
                              min(kFC / 16, ks2_total - c * (kFC / 16)));
     }
   };
-  // both weight streams start inside the LayerNorm prologue, right behind the x-row loads
-  auto start_streams = [&]() {
-    if (producer) {
-      if (wl < nft) fill1(phys(0) * 4 + wl);
+  // both weight streams of a stage start one phase ahead: inside the prologue / the previous stage's row pass
+  auto start_streams = [&](const WPtrs& W) {
+    if constexpr (producer) {
+      if (wl < nft) fill1(W, phys(0) * 4 + wl);
     } else {
-      fill2(phys(0));
+      fill2(W, phys(0));
     }
   };
-  rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, ln_g, ln_b, start_streams);
+  // stage parameters by SELECT, never by a runtime index into the by-value argument block (which would force
+  // the whole block into scratch memory)
+#define EEC_STAGE_FIELD(si, f) ((si) == 0 ? a.st[0].f : a.st[1].f)
+  auto wptrs = [&](int si) {
+    return WPtrs{EEC_STAGE_FIELD(si, w1p), EEC_STAGE_FIELD(si, w2p), EEC_STAGE_FIELD(si, w1f8), EEC_STAGE_FIELD(si, w2f8)};
+  };
+
+  unsigned sink_front = 0;
+  // ---- planes of stage 0 ----
+  if constexpr (FNP != 0) {
+    WRing<FNP, kDPF, 1> rp;
+    ring_fill<FNP, kDPF, 1>(rp, a.pw2.wp + (size_t)w * (kD / 16) * 128 + lane, 0, kD / 16);
+#if EEC_WARM_SLOTS > 0
+    {  // stage 0's weights are cold in this XCD's L2: fetch this workgroup's share while the conv front runs
+      const WPtrs W0 = wptrs(0);
+      const size_t wbytes = NP == 8 ? (size_t)(F / 32) * 4 * kF8Rec * 16 : (size_t)F * kD * 2 * (NP == 3 ? 2 : 1);
+      unsigned t = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        t ^= touch_share(NP == 8 ? (const void*)W0.w1f8 : (const void*)W0.w1p, wbytes, wl, j);
+        t ^= touch_share(NP == 8 ? (const void*)W0.w2f8 : (const void*)W0.w2p, wbytes, wl, j);
+      }
+      sink_front = t;
+    }
+#endif
+    dw_front<FNP>(smem, a.dw, M, row0);
+    float4 xr[8];  // residual rows: requested now, consumed after the pointwise-2 GEMM
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int row = row0 + w * 8 + i;
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // conv planes complete; the staged GLU rows / taps are dead
+    f32x16 accp[2][1];
+    pw2_gemm<FNP>(accp, smem, a.pw2, rp);
+    start_streams(wptrs(0));
+    acc_swapped_to_etile(lds_e, accp);
+    __syncthreads();  // tile complete; every wave is done reading the conv planes
+    chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
+  } else {
+    const WPtrs W0 = wptrs(0);
+    rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, a.st[0].ln_g, a.st[0].ln_b, [&]() { start_streams(W0); });
+  }
   TL_STAMP();  // 1: prologue done
   __syncthreads();
   TL_STAMP();  // 2: after prologue barrier
 
-  // The two roles run separate loops (so neither carries the other's registers); both execute
-  // exactly nslots workgroup barriers.  Pipeline: chunk c is multiplied (GEMM1) in slot c, SiLU'd
-  // and written to H[c & 1] in slot c+1 -- inside the k-loop of GEMM1(c+1), two values per k-step in
-  // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
+  [[maybe_unused]] WRing<(QNP ? QNP : 1), kLPF> rq;  // tail: first k-steps of this wave's Q weight tile
+  unsigned sink = 0;  // keeps the L2 warm-up loads alive
   const int nslots = nchunk + 2;
   f32x16 acc2c[2][2];  // consumers' [64 x 64] output accumulators (unused by producers)
-  if (producer) {
-    // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
-    auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
-      const int mt = step >> 3, q = step & 7;
-      const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
-      constexpr int SNP = NP == 1 ? 1 : 3;
-      const hl2_t sp = ACT == 0 ? split2<SNP>(silu_exp2(u0), silu_exp2(u1)) : split2<SNP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
-      if ((q & 1) == 0) {
-        keep_hi = sp.hi;
-        keep_lo = sp.lo;
-      } else {
-        char* dst = hb + (mt * 32 + (lane & 31)) * kHLd + (wl * 32 + 4 * hh) * 2 + (q >> 1) * 16;
-        h4 hi, lo;
-        hi.xy = keep_hi, hi.zw = sp.hi, lo.xy = keep_lo, lo.zw = sp.lo;
-        *(h4*)dst = hi;
-        if (NP == 3) *(h4*)(dst + kHPlane) = lo;
-        if (NP == 8) {
-          const uint2 lb = __builtin_bit_cast(uint2, lo);
-          *(unsigned*)(hb + kHPlane + (mt * 32 + (lane & 31)) * kH8Ld + lo8_pos(wl * 32 + 4 * hh + (q >> 1) * 8)) =
-              __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
-        }
-      }
-    };
-    auto init_bias = [&](f32x16 (&acc)[2][1], int ft) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          acc[mt][0][4 * g + 0] = bb.x;
-          acc[mt][0][4 * g + 1] = bb.y;
-          acc[mt][0][4 * g + 2] = bb.z;
-          acc[mt][0][4 * g + 3] = bb.w;
-        }
-      }
-    };
-    // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
-    auto slot = [&](int s, f32x16 (&cur)[2][1], f32x16 (&prev)[2][1]) {
-      const int ft = (s < nchunk ? phys(s) : s) * 4 + wl;  // s >= nchunk: no GEMM1 (ft is out of range)
-      const bool do_gemm = s < nchunk && ft < nft;
-      const bool do_silu = s >= 1 && s - 1 < nchunk && phys(s - 1) * 4 + wl < nft;
-      char* hb_prev = lds_h + ((s - 1) & 1) * 2 * kHPlane;
-      h2 khi, klo;
-      if (do_gemm) {
-        init_bias(cur, ft);
-        const uint4* w1_lane = w1p + (size_t)ft * (kD / 16) * 128 + lane;
-        const char* a8_lane = smem + kAPlane + (lane & 31) * kA8Ld + hh * 32;
-        if (do_silu) {
-          auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
-          if constexpr (NP == 8)
-            gemm_ring_f8<4, 1, true, kPF1, decltype(side), 5>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(ft), 0, r1, wg1, side);
-          else
-            gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
-                                                                                     0, r1, side);
+  static_for<NS>([&](auto si_tag) {
+    constexpr int si = decltype(si_tag)::value;  // NS is a template parameter and the loop is unrolled: as a runtime loop it makes
+                                     // every ring and accumulator loop-carried (~250 spilled VGPRs in the hot loops)
+    const WPtrs W = wptrs(si);
+    const float* __restrict__ b1s = EEC_STAGE_FIELD(si, b1);
+    // The two roles run separate loops (so neither carries the other's registers); both execute
+    // exactly nslots workgroup barriers.  Pipeline: chunk c is multiplied (GEMM1) in slot c, SiLU'd
+    // and written to H[c & 1] in slot c+1 -- inside the k-loop of GEMM1(c+1), two values per k-step in
+    // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
+    if constexpr (producer) {
+      // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
+      auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
+        const int mt = step >> 3, q = step & 7;
+        const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
+        constexpr int SNP = NP == 1 ? 1 : 3;
+        const hl2_t sp = ACT == 0 ? split2<SNP>(silu_exp2(u0), silu_exp2(u1)) : split2<SNP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
+        if ((q & 1) == 0) {
+          keep_hi = sp.hi;
+          keep_lo = sp.lo;
         } else {
-          if constexpr (NP == 8)
-            gemm_ring_f8<4, 1, true, kPF1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(ft), 0, r1, wg1);
-          else
-            gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
+          char* dst = hb + (mt * 32 + (lane & 31)) * kHLd + (wl * 32 + 4 * hh) * 2 + (q >> 1) * 16;
+          h4 hi, lo;
+          hi.xy = keep_hi, hi.zw = sp.hi, lo.xy = keep_lo, lo.zw = sp.lo;
+          *(h4*)dst = hi;
+          if (NP == 3) *(h4*)(dst + kHPlane) = lo;
+          if (NP == 8) {
+            const uint2 lb = __builtin_bit_cast(uint2, lo);
+            *(unsigned*)(hb + kHPlane + (mt * 32 + (lane & 31)) * kH8Ld + lo8_pos(wl * 32 + 4 * hh + (q >> 1) * 8)) =
+                __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+          }
         }
-        if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(phys(s + 1) * 4 + wl);  // next chunk's W1 stream
-      } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
+      };
+      auto init_bias = [&](f32x16 (&acc)[2][1], int ft) {
 #pragma unroll
-        for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
-      }
-      TL_STAMP();  // producer: slot work done
-      __syncthreads();
-      TL_STAMP();  // producer: barrier passed
-    };
-    f32x16 accA[2][1], accB[2][1];
-    for (int s = 0; s < nslots; s += 2) {
-      slot(s, accA, accB);
-      if (s + 1 < nslots) slot(s + 1, accB, accA);
-    }
-  } else {
-    f32x16 (&acc2)[2][2] = acc2c;
-    zero_acc(acc2);
-    for (int s = 0; s < nslots; ++s) {
-      if (s >= 2) {
-        const int cl = s - 2, c = phys(cl);  // logical slot chunk (picks the H buffer) / physical hidden chunk
-        const char* h_lane = lds_h + (cl & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
-        const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
-        const uint4* w2_lane = w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
-        if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
-          const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
-          gemm_ring_f8<2, 2, false, kPF2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(c), w2f8_nt, r2, wg2);
-        } else if (ks2 == kFC / 16) {
-          gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
-        } else {
-          gemm_plain<RNP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+        for (int g = 0; g < 4; ++g) {
+          const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            acc[mt][0][4 * g + 0] = bb.x;
+            acc[mt][0][4 * g + 1] = bb.y;
+            acc[mt][0][4 * g + 2] = bb.z;
+            acc[mt][0][4 * g + 3] = bb.w;
+          }
         }
-        if (cl + 1 < nchunk) fill2(phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
+      };
+      // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
+      auto slot = [&](int s, f32x16 (&cur)[2][1], f32x16 (&prev)[2][1]) {
+        const int ft = (s < nchunk ? phys(s) : s) * 4 + wl;  // s >= nchunk: no GEMM1 (ft is out of range)
+        const bool do_gemm = s < nchunk && ft < nft;
+        const bool do_silu = s >= 1 && s - 1 < nchunk && phys(s - 1) * 4 + wl < nft;
+        char* hb_prev = lds_h + ((s - 1) & 1) * 2 * kHPlane;
+        h2 khi, klo;
+        if (do_gemm) {
+          init_bias(cur, ft);
+          const uint4* w1_lane = W.w1p + (size_t)ft * (kD / 16) * 128 + lane;
+          const char* a8_lane = smem + kAPlane + (lane & 31) * kA8Ld + hh * 32;
+          if (do_silu) {
+            auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
+            if constexpr (NP == 8)
+              gemm_ring_f8<4, 1, true, kPF1, decltype(side), 5, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
+            else
+              gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
+                                                                                       0, r1, side);
+          } else {
+            if constexpr (NP == 8)
+              gemm_ring_f8<4, 1, true, kPF1, NoSide, 0, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
+            else
+              gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
+          }
+          if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(W, phys(s + 1) * 4 + wl);  // next chunk's W1 stream
+        } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
+#pragma unroll
+          for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
+        }
+        TL_STAMP();  // producer: slot work done
+        __syncthreads();
+        TL_STAMP();  // producer: barrier passed
+      };
+      f32x16 accA[2][1], accB[2][1];
+      for (int s = 0; s < nslots; s += 2) {
+        slot(s, accA, accB);
+        if (s + 1 < nslots) slot(s + 1, accB, accA);
       }
-      TL_STAMP();  // consumer: slot work done
-      __syncthreads();
-      TL_STAMP();  // consumer: barrier passed
-    }
-  }
-  // residual rows of this wave: issued now, consumed after the tile exchange below
-  float4 xr[8];
+    } else {
+      f32x16 (&acc2)[2][2] = acc2c;
+      zero_acc(acc2);
+#if EEC_WARM_SLOTS > 0
+      unsigned warm[4] = {0u, 0u, 0u, 0u};
+#endif
+      for (int s = 0; s < nslots; ++s) {
+#if EEC_WARM_SLOTS > 0
+        if (s == nslots - EEC_WARM_SLOTS) {
+          // L2 warm-up for the stage boundary, in the consumers' slack: this workgroup's 1/32 share of what the next
+          // phase streams (the next stage's weights, or the in_proj weights of the tail).  Without it the boundary
+          // starts with a burst of cold misses (each XCD fetches its own copy: ~26 MB at once).
+          if constexpr (si + 1 < NS) {
+            const WPtrs Wn = wptrs(si + 1);
+            const size_t wbytes = NP == 8 ? (size_t)(F / 32) * 4 * kF8Rec * 16 : (size_t)F * kD * 2 * (NP == 3 ? 2 : 1);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = row0 + w * 8 + i;
-    xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  // the consumers hold the [64, 256] result: stage it through the fp32 tile (aliases the A planes;
-  // the last barrier of the loops guarantees no producer still reads them)
-  if (!producer) acc_to_etile<2>(smem, acc2c, wl * 64, b2);
-  __syncthreads();
-
-  float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (FINAL_LN) {
-    g = ((const float4*)fin_g)[lane];
-    bt = ((const float4*)fin_b)[lane];
-  }
-  {
-    float4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      v[i] = xr[i];
-      const float4 e = *(const float4*)(smem + (w * 8 + i) * kELd + lane * 16);
-      v[i].x += res_scale * e.x;
-      v[i].y += res_scale * e.y;
-      v[i].z += res_scale * e.z;
-      v[i].w += res_scale * e.w;
+            for (int j = 0; j < 2; ++j) {
+              warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, wl, j);
+              warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, wl, j);
+            }
+          } else if constexpr (QNP != 0) {
+            warm[0] = touch_share(a.qkv.wp, (size_t)3 * kD * kD * 2 * (QNP == 3 ? 2 : 1), wl, 0);
+          }
+        }
+#endif
+        if (s >= 2) {
+          const int cl = s - 2, c = phys(cl);  // logical slot chunk (picks the H buffer) / physical hidden chunk
+          const char* h_lane = lds_h + (cl & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
+          const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
+          const uint4* w2_lane = W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
+          if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
+            const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
+            gemm_ring_f8<2, 2, false, kPF2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
+          } else if (ks2 == kFC / 16) {
+            gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+          } else {
+            gemm_plain<RNP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+          }
+          if (cl + 1 < nchunk) fill2(W, phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
+        }
+        TL_STAMP();  // consumer: slot work done
+        __syncthreads();
+        TL_STAMP();  // consumer: barrier passed
+      }
+#if EEC_WARM_SLOTS > 0
+      sink ^= warm[0] ^ warm[1] ^ warm[2] ^ warm[3];
+#endif
     }
-    if (FINAL_LN) layer_norm_rows<8>(v, g, bt);
+    // ---- stage epilogue ----
+    // residual rows of this wave: issued now, consumed after the tile exchange below (for a second stage
+    // they are the rows this very thread stored in the previous row pass)
+    float4 xr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = row0 + w * 8 + i;
-      if (row < M) ((float4*)(x + (size_t)row * kD))[lane] = v[i];
+      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
     }
-  }
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr bool more = si + 1 < NS;
+    // the consumers hold the [64, 256] result: stage it through the fp32 tile (the last barrier of the
+    // loops guarantees that nobody still reads the H buffers it aliases)
+    TL_STAMP();  // residual loads issued
+    if constexpr (!producer) acc_to_etile<2>(lds_e, acc2c, wl * 64, EEC_STAGE_FIELD(si, b2));
+    TL_STAMP();  // exchange tile written
+    // the next phase's weight streams start only now, when the accumulators are dead (issued earlier, their
+    // registers push the allocator into spilling, and scratch reloads queue behind these cold loads); the
+    // warm-up above has already brought this data into the XCD's L2
+    if constexpr (more) {
+      start_streams(wptrs(1));
+    } else if constexpr (QNP != 0) {
+      ring_fill<QNP, kLPF, 1>(rq, wfrag_lane(a.qkv.wp, w), 0, kD / 16);
+    }
+    __syncthreads();
+    TL_STAMP();  // barrier
+    const float res_scale = EEC_STAGE_FIELD(si, res_scale);
+    const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
+    float* tap = EEC_STAGE_FIELD(si, tap);
+    if constexpr (more) {  // only stage 0 can have a successor
+      chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b);
+    } else if constexpr (QNP != 0) {
+      chain_rowpass<QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b);
+    } else {
+      chain_rowpass<0, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, nullptr, nullptr);
+    }
+    TL_STAMP();  // row pass done
+    if (more || QNP != 0) __syncthreads();  // next planes complete; the exchange tile is free again
+    TL_STAMP();  // stage epilogue + row pass done
+  });
+  if constexpr (QNP != 0) qkv_body<QNP>(smem, a.qkv, row0, rq);
+  if ((sink ^ sink_front) == 0x9e3779b9u && M == -7) x[0] = 0.f;  // never true: the warm-up loads must not be optimised away
   TL_STAMP();  // last: epilogue done
+  };
+  if (is_producer)
+    run(BoolTag<true>{});
+  else
+    run(BoolTag<false>{});
 }
 
 #ifdef EEC_TIMELINE
 extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
   static unsigned long long* dev = nullptr;
   if (!dev) {
-    if (hipMalloc(&dev, 8 * 2 * 64 * 8) != hipSuccess) return 1;
-    (void)hipMemset(dev, 0, 8 * 2 * 64 * 8);
+    if (hipMalloc(&dev, 8 * 2 * 128 * 8) != hipSuccess) return 1;
+    (void)hipMemset(dev, 0, 8 * 2 * 128 * 8);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_timeline), &dev, sizeof(dev));
     return 0;
   }
@@ -318,35 +489,51 @@ extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
 }
 #endif
 
-template <int NP, bool FL, int ACT>
-static hipError_t launch_ffn_t(const FfnArgs& a, hipStream_t st) {
-  auto k = ffn_kernel<NP, FL, ACT>;
+template <int NP, int ACT, int FNP, int QNP, int NS>
+static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
+  auto k = ffn_chain_kernel<NP, ACT, FNP, QNP, NS>;
+  constexpr int lds = FNP != 0 ? (kDwLds > kFfnLds ? kDwLds : kFfnLds) : kFfnLds;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kFfnLds);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int grid = (a.M + kTileRows - 1) / kTileRows;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), kFfnLds, st, a.x, a.M, a.res_scale, a.ln_g, a.ln_b, a.w1p, a.b1, a.w2p,
-                     a.b2, a.F, a.fin_g, a.fin_b, a.w1f8, a.w2f8);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), lds, st, a);
   return hipGetLastError();
 }
 
-hipError_t launch_ffn(const FfnArgs& a, int np_in, hipStream_t st) {
-  int np = np_in;
-  const bool fl = a.fin_g != nullptr;
-  if (np == 8 && (a.F % kFC != 0 || !a.w1f8 || !a.w2f8)) np = 3;  // the f8 stream needs whole 128-wide chunks
-  if (np == 8) {
-    if (a.relu) return fl ? launch_ffn_t<8, true, 1>(a, st) : launch_ffn_t<8, false, 1>(a, st);
-    return fl ? launch_ffn_t<8, true, 0>(a, st) : launch_ffn_t<8, false, 0>(a, st);
+// np: FFN format (1, 3, 8); np_o: format of the optional front / tail (1 or 3)
+hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_o, bool front, bool tail, bool relu, hipStream_t st) {
+  ChainArgs a = a_in;
+  if (a.nstage < 1 || a.nstage > 2) return hipErrorInvalidValue;
+  for (int i = 0; i < a.nstage; ++i)
+    if (np == 8 && (a.F % kFC != 0 || !a.st[i].w1f8 || !a.st[i].w2f8)) np = 3;  // the f8 stream needs whole 128-wide chunks
+  if (relu) {
+    if (front || tail || a.nstage != 1) return hipErrorInvalidValue;
+    if (np == 8) return launch_chain_t<8, 1, 0, 0, 1>(a, st);
+    if (np == 3) return launch_chain_t<3, 1, 0, 0, 1>(a, st);
+    return launch_chain_t<1, 1, 0, 0, 1>(a, st);
   }
-  if (a.relu) {
-    if (np == 3) return fl ? launch_ffn_t<3, true, 1>(a, st) : launch_ffn_t<3, false, 1>(a, st);
-    return fl ? launch_ffn_t<1, true, 1>(a, st) : launch_ffn_t<1, false, 1>(a, st);
-  }
-  if (np == 3) return fl ? launch_ffn_t<3, true, 0>(a, st) : launch_ffn_t<3, false, 0>(a, st);
-  return fl ? launch_ffn_t<1, true, 0>(a, st) : launch_ffn_t<1, false, 0>(a, st);
+  const int f = front ? np_o : 0, q = tail ? np_o : 0;
+#define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
+  if (np == NP_ && f == F_ && q == Q_)                                                                   \
+    return a.nstage == 2 ? launch_chain_t<NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<NP_, 0, F_, Q_, 1>(a, st);
+  EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 3, 3)
+  EEC_CHAIN_CASE(3, 0, 0) EEC_CHAIN_CASE(3, 3, 0) EEC_CHAIN_CASE(3, 0, 3) EEC_CHAIN_CASE(3, 3, 3)
+  EEC_CHAIN_CASE(1, 0, 0) EEC_CHAIN_CASE(1, 3, 0) EEC_CHAIN_CASE(1, 0, 3) EEC_CHAIN_CASE(1, 3, 3)
+  EEC_CHAIN_CASE(1, 1, 0) EEC_CHAIN_CASE(1, 0, 1) EEC_CHAIN_CASE(1, 1, 1)
+#undef EEC_CHAIN_CASE
+  return hipErrorInvalidValue;
+}
+
+// single stand-alone stage (the unfused plan and the legacy encoder)
+hipError_t launch_ffn(const FfnArgs& f, int np, hipStream_t st) {
+  ChainArgs a{};
+  a.x = f.x, a.M = f.M, a.F = f.F, a.nstage = 1;
+  a.st[0] = FfnStage{f.ln_g, f.ln_b, f.w1p, f.b1, f.w2p, f.b2, f.fin_g, f.fin_b, f.w1f8, f.w2f8, f.res_scale, nullptr};
+  return launch_ffn_chain(a, np, 3, false, false, f.relu, st);
 }
 
 }  // namespace eec

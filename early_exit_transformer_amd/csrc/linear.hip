@@ -8,41 +8,9 @@
 //   proj_residual_kernel x += A . W^T + b   (attention out_proj a6; conv pointwise-2 a7)
 //   proj_glu_kernel      out_proj + residual -> LN -> pointwise-1 (N=512) -> GLU -> fp16, one launch (a6, a7)
 //   head_kernel          exit head: Linear(D,V) -> log_softmax -> fp32 log-probs                    (a9)
-#include "eec_kernels.h"
+#include "eec_blocks.h"
 
 namespace eec {
-
-constexpr int kLinThreads = 512;
-constexpr int kLinLds = 2 * kAPlane;  // 67584: the activation planes only
-#ifndef EEC_LPF
-#define EEC_LPF 4
-#endif
-constexpr int kLPF = EEC_LPF;  // weight fragments (1 KiB each per plane) a wave keeps in flight
-
-__device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-order of an accumulator-fed operand
-  return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
-}
-
-// acc[mt][0][4g + j] <- bias[n0 + 8g + 4hh + j]  (swapped orientation: register = output feature)
-template <int MT>
-__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MT][1], const float* __restrict__ bias_n0) {
-  const int hh = lane_id() >> 5;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 bb = *(const float4*)(bias_n0 + 8 * g + 4 * hh);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      acc[mt][0][4 * g + 0] = bb.x;
-      acc[mt][0][4 * g + 1] = bb.y;
-      acc[mt][0][4 * g + 2] = bb.z;
-      acc[mt][0][4 * g + 3] = bb.w;
-    }
-  }
-}
-
-__device__ __forceinline__ const uint4* wfrag_lane(const uint4* wp, int nt) {
-  return wp + (size_t)nt * (kD / 16) * 128 + lane_id();
-}
 
 EEC_TL_DEFINE(qkv)
 EEC_TL_DEFINE(glu)
@@ -50,85 +18,16 @@ EEC_TL_DEFINE(glu)
 template <int NP>
 __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  const int w = wave_id();
   const int row0 = blockIdx.x * kTileRows;
-  const int dh = kD / a.H;
-  const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
-
-  WRing<NP, kLPF> rq, rk;
+  WRing<NP, kLPF> rq;
   EEC_TL_STAMP(qkv, 0);
   rows_f32_to_planes<NP, true, 8>(smem, a.x, row0, a.M, a.ln_g, a.ln_b,
                                   [&]() { ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, w), 0, kD / 16); });
   EEC_TL_STAMP(qkv, 1);
   __syncthreads();
   EEC_TL_STAMP(qkv, 2);
-
-  // row -> (utterance, frame) of this lane's two frames
-  int rb[2], rt[2];
-  bool ok[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int row = row0 + mt * 32 + (lane & 31);
-    ok[mt] = row < a.M;
-    rb[mt] = row / a.Tq;
-    rt[mt] = row - rb[mt] * a.Tq;
-  }
-  const int n0 = 32 * w, hd = n0 / dh, d0 = n0 - hd * dh + 4 * hh;
-
-  f32x16 acc[2][1];
-  // ---- Q ----
-  ring_fill<NP, kLPF, 1>(rk, wfrag_lane(a.wp, 8 + w), 0, kD / 16);
-  acc_init_bias<2>(acc, a.bias + n0);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, rq);
-  EEC_TL_STAMP(qkv, 3);
-  ring_fill<NP, kLPF, 1>(rq, wfrag_lane(a.wp, 16 + w), 0, kD / 16);  // V weights, in flight during the K pass
-  {
-    const float scale = kLog2e * rsqrtf((float)dh);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-      if (ok[mt]) {
-        half_t* dst = a.q + ((size_t)(rb[mt] * a.H + hd) * a.Tp + rt[mt]) * dh + d0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          h4 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = to_half_sat(acc[mt][0][4 * g + j] * scale);
-          *(h4*)(dst + 8 * g) = o;
-        }
-      }
-  }
-  // ---- K ----
-  EEC_TL_STAMP(qkv, 4);
-  acc_init_bias<2>(acc, a.bias + kD + n0);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 8 + w), 0, rk);
-  EEC_TL_STAMP(qkv, 5);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-    if (ok[mt]) {
-      half_t* dst = a.k + ((size_t)(rb[mt] * a.H + hd) * a.Tp + rt[mt]) * dh + d0;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        h4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = to_half_sat(acc[mt][0][4 * g + j]);
-        *(h4*)(dst + 8 * g) = o;
-      }
-    }
-  // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
-  EEC_TL_STAMP(qkv, 6);
-  acc_init_bias<2>(acc, a.bias + 2 * kD + n0);
-  gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, 16 + w), 0, rq);
-  EEC_TL_STAMP(qkv, 7);
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-    if (ok[mt]) {
-      half_t* dst = a.vt + ((size_t)(rb[mt] * a.H + hd) * dh + d0) * a.Tp + vt_perm(rt[mt]);
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dst[(size_t)(8 * g + j) * a.Tp] = to_half_sat(acc[mt][0][4 * g + j]);
-    }
-  EEC_TL_STAMP(qkv, 8);
+  qkv_body<NP>(smem, a, row0, rq);
 }
 
 template <typename K>

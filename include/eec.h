@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 2
+#define EEC_ABI_VERSION 3
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -140,7 +140,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
  * when enabled, every kernel launch of eec_encoder_forward is bracketed by hipEventRecord on the
  * launch stream; eec_encoder_profile_read synchronises the recorded events and returns the summed
  * milliseconds and launch counts per kernel class, index = EEC_KC_*. */
-enum { EEC_KC_STEM = 0, EEC_KC_FFN, EEC_KC_QKV, EEC_KC_ATTN, EEC_KC_PROJ_GLU, EEC_KC_PROJ, EEC_KC_DW_PW2, EEC_KC_HEAD, EEC_KC_COUNT };
+enum { EEC_KC_STEM = 0, EEC_KC_FFN, EEC_KC_QKV, EEC_KC_ATTN, EEC_KC_PROJ_GLU, EEC_KC_PROJ, EEC_KC_DW_PW2, EEC_KC_HEAD, EEC_KC_CHAIN, EEC_KC_COUNT };
 int eec_encoder_set_profiling(eec_encoder* enc, int enable, int max_launches);
 int eec_encoder_profile_read(eec_encoder* enc, double* ms_by_class, long long* launches_by_class, int n_classes);
 

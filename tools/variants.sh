@@ -6,7 +6,7 @@ for v in "$@"; do
   python - <<PY
 import json
 try:
-    d=json.load(open("gpurun_out/var_$v.json")); print("$v", d["ms_per_step"], "fwd", d["forward_only"]["ms_per_step"], {k:v["avg_us"] for k,v in d["kernel_time"].items()})
+    d=json.load(open("gpurun_out/var_$v.json")); print("$v", d["ms_per_step"], "fwd", d["forward_only"]["ms_per_step"], {k:(v["avg_us"],v["n"]) for k,v in d["kernel_time"].items() if v["n"]})
 except Exception as e: print("$v failed", e)
 PY
 done
