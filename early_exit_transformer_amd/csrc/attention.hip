@@ -3,7 +3,7 @@
 //     O[b, t, h*dh + d] = sum_k softmax_k( q[t].k[k] / sqrt(dh) | k < len[b] ) * v[k][d]
 // Only keys are masked; padded query rows are computed like any other (reference behaviour).
 //
-// Workgroup = one (utterance, head, 128-query block); wave = 32 queries.  Both products
+// Workgroup = one (utterance, head, 256-query block); wave = 32 queries.  Both products
 // keep the query on the MFMA lane:
 //     S^T[key][q] = K . Q^T            (A = K fragment from LDS, B = Q fragment in registers)
 //     O^T[d][q]  += V^T . P^T          (A = V^T fragment from LDS, B = P straight from the
@@ -30,8 +30,31 @@ struct AttnLds {
 };
 
 EEC_TL_DEFINE(attn)
+#ifdef EEC_TL
+__device__ unsigned long long g_tl_attn_all[2048];  // [block][start, end] of wave 0 (first 1024 workgroups)
+extern "C" int eec_tl_read_attn_all(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tl_attn_all), sizeof(g_tl_attn_all));
+}
+#define EEC_TL_ALL(i)                                                                               \
+  do {                                                                                              \
+    const int b_ = (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));           \
+    if (threadIdx.x == 0 && b_ < 1024) g_tl_attn_all[b_ * 2 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define EEC_TL_ALL(i)
+#endif
+// Workgroup shape: kAttnWaves waves x 32 queries.  8 waves (256 queries) means K and V^T of an (utterance, head)
+// pair are staged ONCE when T' <= 256; with KB = 2 the kernel needs < 128 VGPRs, so two such workgroups (16
+// waves) share a CU and every workgroup of the BASELINE shape is resident in a single round.
+#ifndef EEC_ATTN_KB
+#define EEC_ATTN_KB 2
+#define EEC_ATTN_WAVES 8
+#define EEC_ATTN_OCC 4
+#endif
+constexpr int kAttnWaves = EEC_ATTN_WAVES, kAttnThreads = 64 * kAttnWaves;
 template <int DH, int NP>
-__global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
+__global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void attn_kernel(AttnArgs a) {
   using L = AttnLds<DH>;
   constexpr int KSQ = DH / 16;  // k-steps of the score product
   constexpr int DT = DH / 32;   // 32-row tiles of O^T
@@ -42,11 +65,12 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y;
   const int bh = b * a.H + hd;
-  const int q0 = (blockIdx.x * 4 + w) * 32;
+  const int q0 = (blockIdx.x * kAttnWaves + w) * 32;
   const bool active = q0 < a.Tq;  // wave-uniform
   const int len = min(a.enc_len[b], a.Tq);
 
   EEC_TL_STAMP(attn, 0);
+  EEC_TL_ALL(0);
   h8 qf[KSQ];
   if (active) {
     const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + r) * DH + 8 * hh;
@@ -69,30 +93,30 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
     {
       constexpr int KP = DH / 8;  // 16-byte pieces per K row
       constexpr int VP = kKC / 8;
-      constexpr int KIT = kKC * KP / kThreads, VIT = DH * VP / kThreads;
-      static_assert(kKC * KP % kThreads == 0 && DH * VP % kThreads == 0, "staging loops assume whole passes");
+      constexpr int KIT = kKC * KP / kAttnThreads, VIT = DH * VP / kAttnThreads;
+      static_assert(kKC * KP % kAttnThreads == 0 && DH * VP % kAttnThreads == 0, "staging loops assume whole passes");
       uint4 kv[KIT], vv[VIT];
 #pragma unroll
       for (int it = 0; it < KIT; ++it) {
-        const int p = it * kThreads + threadIdx.x, row = p / KP, c = p % KP;
+        const int p = it * kAttnThreads + threadIdx.x, row = p / KP, c = p % KP;
         kv[it] = make_uint4(0, 0, 0, 0);
         if (kc0 + row < a.Tp) kv[it] = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
       }
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
-        const int p = it * kThreads + threadIdx.x, row = p / VP, c = p % VP;
+        const int p = it * kAttnThreads + threadIdx.x, row = p / VP, c = p % VP;
         vv[it] = make_uint4(0, 0, 0, 0);
         if (kc0 + c * 8 < a.Tp) vv[it] = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int it = 0; it < KIT; ++it) {
-        const int p = it * kThreads + threadIdx.x, row = p / KP, c = p % KP;
+        const int p = it * kAttnThreads + threadIdx.x, row = p / KP, c = p % KP;
         *(uint4*)(lds_k + row * L::KLD + c * 16) = kv[it];
       }
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
-        const int p = it * kThreads + threadIdx.x, row = p / VP, c = p % VP;
+        const int p = it * kAttnThreads + threadIdx.x, row = p / VP, c = p % VP;
         *(uint4*)(lds_v + row * L::VLD + c * 16) = vv[it];
       }
     }
@@ -101,10 +125,10 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
     EEC_TL_STAMP(attn, 2);
     if (!active) continue;
     const int nkt = (min(len - kc0, kKC) + 31) / 32;
-    // online softmax over blocks of KB = 4 key tiles (128 keys): the per-block overhead (cross-half
-    // max, rescale of O, running sums) is paid once per 128 keys; the key mask is applied only in a
+    // online softmax over blocks of KB key tiles (32 KB keys): the per-block overhead (cross-half
+    // max, rescale of O, running sums) is paid once per block; the key mask is applied only in a
     // block that actually contains keys >= len (wave-uniform test)
-    constexpr int KB = 4;
+    constexpr int KB = EEC_ATTN_KB;
     for (int kt0 = 0; kt0 < nkt; kt0 += KB) {
       f32x16 s[KB];
 #pragma unroll
@@ -183,6 +207,7 @@ __global__ __launch_bounds__(kThreads) void attn_kernel(AttnArgs a) {
       }
   }
   EEC_TL_STAMP(attn, 4);
+  EEC_TL_ALL(1);
 }
 
 template <int DH, int NP>
@@ -191,7 +216,7 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
   constexpr int lds = AttnLds<DH>::TOTAL;
   hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.Tq + 127) / 128, a.H, a.B), dim3(kThreads), lds, st, a);
+  hipLaunchKernelGGL(k, dim3((a.Tq + 32 * kAttnWaves - 1) / (32 * kAttnWaves), a.H, a.B), dim3(kAttnThreads), lds, st, a);
   return hipGetLastError();
 }
 
