@@ -129,9 +129,10 @@ size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T);
  *   out      [E, B, T', V] fp32 log-probabilities (written in place, no torch.cat)
  *   taps_opt [E, B, T', D] fp32 or NULL: pre-head activations after each exit group
  *            (what full_conformer._encoder_(src, lengths, n) returns, early_exit.py:719-737)
- *   stop_after: <0 = run everything; otherwise stop after that many sub-steps
- *            (0 = stem, then per layer: ffn1, attention, conv, ffn2; legacy: attention, ffn) -- test hook; the current
- *            residual stream is then left in x_dbg_opt [B*T', D] if given. */
+ *   stop_after: <0 = run everything with the production launch plan (Conformer: 3 launches per layer, the
+ *            row-tile-local steps fused into one "chain" kernel); otherwise stop after that many
+ *            sub-steps (0 = stem, then per layer: ffn1, attention, conv, ffn2; legacy: attention, ffn), each sub-step
+ *            its own launch -- test hook; the current residual stream is then left in x_dbg_opt [B*T', D] if given. */
 int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T,
                         int precision, float* out, float* taps_opt, void* workspace, size_t workspace_bytes,
                         int stop_after, float* x_dbg_opt, void* stream);
@@ -139,7 +140,8 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
 /* Measurement hook (no reference counterpart; the reference has no profiler hooks):
  * when enabled, every kernel launch of eec_encoder_forward is bracketed by hipEventRecord on the
  * launch stream; eec_encoder_profile_read synchronises the recorded events and returns the summed
- * milliseconds and launch counts per kernel class, index = EEC_KC_*. */
+ * milliseconds and launch counts per kernel class, index = EEC_KC_* (EEC_KC_CHAIN: the fused chain kernel of the
+ * production plan; EEC_KC_FFN / _QKV / _DW_PW2 / _PROJ: the same steps as separate launches of the sub-step plan). */
 enum { EEC_KC_STEM = 0, EEC_KC_FFN, EEC_KC_QKV, EEC_KC_ATTN, EEC_KC_PROJ_GLU, EEC_KC_PROJ, EEC_KC_DW_PW2, EEC_KC_HEAD, EEC_KC_CHAIN, EEC_KC_COUNT };
 int eec_encoder_set_profiling(eec_encoder* enc, int enable, int max_launches);
 int eec_encoder_profile_read(eec_encoder* enc, double* ms_by_class, long long* launches_by_class, int n_classes);
