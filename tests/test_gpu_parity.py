@@ -124,6 +124,25 @@ def test_every_substep_against_oracle(prec):
         assert err < {"f16x3": 2e-4, "f16f8": 4e-4, "f16": 2e-3}[prec] * max(scale, 1.0), f"sub-step {k}: {err:.3e} (scale {scale:.2f})"
 
 
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "mixed", "f16"])
+def test_fused_plan_equals_substep_plan(prec):
+    """The production plan (3 launches per layer, fused chain kernel) and the sub-step plan (one launch per step,
+    the one test_every_substep_against_oracle walks) run the same arithmetic: their final residual streams differ
+    only by fp32 summation order (the exchange-tile row pass vs accumulator epilogues)."""
+    kw = base_kwargs(n_enc_exits=3, n_enc_layers=2, d_feed_forward=640)  # 5 chunks of 128: odd chunk count
+    _, gpu = make_pair(kw, seed=12)
+    mel, lens = synth.synth_mel(5, 80, 403, seed=12), torch.tensor([403, 402, 300, 77, 5])  # M = 495: ragged last tile
+    gpu.precision = prec
+    with torch.no_grad():
+        out_f, _, x_f = gpu._run_encoder(mel.cuda(), lens, want_x=True)
+        n_sub = 1 + 4 * 6
+        out_s, _, x_s = gpu._run_encoder(mel.cuda(), lens, stop_after=n_sub, want_x=True)
+    out_f, x_f, out_s, x_s = out_f.cpu(), x_f.cpu(), out_s.cpu(), x_s.cpu()
+    assert torch.isfinite(x_f).all() and torch.isfinite(out_f).all()
+    assert (x_f - x_s).abs().max().item() < 2e-5 * max(x_s.abs().max().item(), 1.0)
+    assert (out_f - out_s).abs().max().item() < 5e-5
+
+
 @pytest.mark.parametrize("B,T,lens", [
     (1, 7, [7]),                     # T' = 1: the shortest legal input
     (1, 131, [131]),                 # single utterance, one partial row tile
