@@ -56,6 +56,17 @@ constexpr int kETile = kTileRows * kELd;      // 66560 (aliases the two A planes
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+// Lane index recomputed from nothing (v_mbcnt of the full mask) behind an optimisation barrier: code after a long
+// register-starved loop derives its lane / row indices from THIS value, so the compiler recomputes them (a few
+// VALU ops) instead of keeping what it computed before the loop alive -- i.e. spilled to scratch and reloaded
+// (from DRAM: the weight stream has evicted the scratch lines) at the loop exit.  The wave index for such code
+// comes from an SGPR copy made at kernel entry (wave_id_sgpr()).
+__device__ __forceinline__ int fresh_lane() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+__device__ __forceinline__ int wave_id_sgpr() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // Wave-wide reductions on the DPP crossbar (no LDS traffic, unlike __shfl_xor = ds_bpermute): xor-1 / xor-2
 // inside each quad, half-row and row mirrors -> every lane of a 16-lane row holds the row total; row_bcast15
@@ -538,8 +549,8 @@ __device__ __forceinline__ void layer_norm_rows(float4 (&v)[N], const float4 g, 
 // fp16 hi plane, plus the fp16 lo plane (NP == 3) or the permuted e5m2 lo byte plane (NP == 8).
 // Rows at or beyond M are written as zeros when zero_tail is set (a LayerNorm turns a zero row into beta).
 template <int NP, int N>
-__device__ __forceinline__ void rows_to_planes(char* lds_act, float4 (&v)[N], int rl0, int row0, int M, bool zero_tail) {
-  const int lane = lane_id();
+__device__ __forceinline__ void rows_to_planes(char* lds_act, float4 (&v)[N], int rl0, int row0, int M, bool zero_tail,
+                                               int lane = lane_id()) {
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int rl = rl0 + i;
@@ -594,8 +605,7 @@ __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* _
 // acc[MT=2][NT] (normal orientation, wave owns columns col0 + nt*32 ..) + bias -> fp32 tile in LDS.
 template <int NT>
 __device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2][NT], int col0,
-                                             const float* __restrict__ bias) {
-  const int lane = lane_id();
+                                             const float* __restrict__ bias, int lane = lane_id()) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = col0 + nt * 32 + (lane & 31);

@@ -97,9 +97,9 @@ __device__ __forceinline__ unsigned touch_lines(const void* base, size_t first_l
 }
 // instruction j (0 or 1) of this wave's part of the workgroup's 1/32 share of an array (the workgroups of an
 // XCD -- blockIdx % 8 -- share one L2; a share is at most 2 x 64 lines per wave for the matrices used here)
-__device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, int wl, int j) {
+__device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, int wl, int j, int lane = lane_id()) {
   const size_t n_lines = bytes / 128, per_wg = (n_lines + 31) / 32, per_wave = (per_wg + 3) / 4;
-  const size_t k = (size_t)j * 64 + lane_id();
+  const size_t k = (size_t)j * 64 + lane;
   const size_t ln = ((blockIdx.x >> 3) & 31) * per_wg + wl * per_wave + k;
   return (k < per_wave && ln < n_lines) ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
 }
@@ -131,8 +131,8 @@ template <int NPN, bool HAS_RES>
 __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, float* __restrict__ x, float4 (&xr)[8],
                                               int row0, int M, float scale, const float* __restrict__ fin_g,
                                               const float* __restrict__ fin_b, float* __restrict__ tap,
-                                              const float* __restrict__ nln_g, const float* __restrict__ nln_b) {
-  const int lane = lane_id(), w = wave_id();
+                                              const float* __restrict__ nln_g, const float* __restrict__ nln_b,
+                                              int lane = lane_id(), int w = wave_id()) {
   float4 v[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -154,7 +154,7 @@ __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, flo
   }
   if constexpr (NPN != 0) {
     layer_norm_rows<8>(v, ((const float4*)nln_g)[lane], ((const float4*)nln_b)[lane]);
-    rows_to_planes<NPN, 8>(smem, v, w * 8, row0, M, true);
+    rows_to_planes<NPN, 8>(smem, v, w * 8, row0, M, true, lane);
   }
 }
 
@@ -171,6 +171,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   constexpr int kPF1 = FfnPf<NP>::P1, kPF2 = FfnPf<NP>::P2;
   const int lane = lane_id(), w = wave_id();
   const int hh = lane >> 5, wl = w & 3;
+  const int w_s = wave_id_sgpr();
   const bool is_producer = w >= 4;  // wave-uniform; consumers are the OLDER waves (issue arbitration: priority, then age)
   const int row0 = blockIdx.x * kTileRows;
   const int M = a.M, F = a.F;
@@ -388,16 +389,17 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           // L2 warm-up for the stage boundary, in the consumers' slack: this workgroup's 1/32 share of what the next
           // phase streams (the next stage's weights, or the in_proj weights of the tail).  Without it the boundary
           // starts with a burst of cold misses (each XCD fetches its own copy: ~26 MB at once).
+          const int lane_t = fresh_lane();
           if constexpr (si + 1 < NS) {
             const WPtrs Wn = wptrs(si + 1);
             const size_t wbytes = NP == 8 ? (size_t)(F / 32) * 4 * kF8Rec * 16 : (size_t)F * kD * 2 * (NP == 3 ? 2 : 1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, wl, j);
-              warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, wl, j);
+              warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, w_s & 3, j, lane_t);
+              warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, w_s & 3, j, lane_t);
             }
           } else if constexpr (QNP != 0) {
-            warm[0] = touch_share(a.qkv.wp, (size_t)3 * kD * kD * 2 * (QNP == 3 ? 2 : 1), wl, 0);
+            warm[0] = touch_share(a.qkv.wp, (size_t)3 * kD * kD * 2 * (QNP == 3 ? 2 : 1), w_s & 3, 0, lane_t);
           }
         }
 #endif
@@ -427,19 +429,20 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // ---- stage epilogue ----
     // residual rows of this wave: issued now, consumed after the tile exchange below (for a second stage
     // they are the rows this very thread stored in the previous row pass)
+    const int lane_e = fresh_lane(), w_e = w_s;  // see fresh_lane(): nothing index-like stays live across the chunk loops
     float4 xr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int row = row0 + w * 8 + i;
+      const int row = row0 + w_e * 8 + i;
       xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
+      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane_e];
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr bool more = si + 1 < NS;
     // the consumers hold the [64, 256] result: stage it through the fp32 tile (the last barrier of the
     // loops guarantees that nobody still reads the H buffers it aliases)
     TL_STAMP();  // residual loads issued
-    if constexpr (!producer) acc_to_etile<2>(lds_e, acc2c, wl * 64, EEC_STAGE_FIELD(si, b2));
+    if constexpr (!producer) acc_to_etile<2>(lds_e, acc2c, (w_e & 3) * 64, EEC_STAGE_FIELD(si, b2), lane_e);
     TL_STAMP();  // exchange tile written
     // the next phase's weight streams start only now, when the accumulators are dead (issued earlier, their
     // registers push the allocator into spilling, and scratch reloads queue behind these cold loads); the
@@ -455,11 +458,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
     float* tap = EEC_STAGE_FIELD(si, tap);
     if constexpr (more) {  // only stage 0 can have a successor
-      chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b);
+      chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b, lane_e, w_e);
     } else if constexpr (QNP != 0) {
-      chain_rowpass<QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b);
+      chain_rowpass<QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b, lane_e, w_e);
     } else {
-      chain_rowpass<0, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, nullptr, nullptr);
+      chain_rowpass<0, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, nullptr, nullptr, lane_e, w_e);
     }
     TL_STAMP();  // row pass done
     if (more || QNP != 0) __syncthreads();  // next planes complete; the exchange tile is free again
