@@ -48,6 +48,9 @@ template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF
 #define EEC_PF2_NP8 3
 #endif
 template <> struct FfnPf<8> { static constexpr int P1 = EEC_PF1_NP8, P2 = EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+#ifndef EEC_SIDE_VALU_NP8
+#define EEC_SIDE_VALU_NP8 5  // VALU instructions of the SiLU side work pinned behind each MFMA of GEMM1 (f8 stream)
+#endif
 #ifndef EEC_NW1
 #define EEC_NW1 4
 #endif
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           if (do_silu) {
             auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
             if constexpr (NP == 8)
-              gemm_ring_f8<4, 1, true, kPF1, decltype(side), 5, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
+              gemm_ring_f8<4, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
               gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
                                                                                        0, r1, side);
