@@ -310,3 +310,19 @@ class TestFullSize:
             # the reference mask needs max(lengths) == T inside the sub-batch: utterance 0 is full length
             want = ref(mel[idx], lens[idx])
         assert (out[:, idx] - want).abs().max().item() < TOL["f16x3"]
+
+
+def test_long_utterances_two_key_chunks_default_model():
+    """SURVEY 8d secondary shape: T = 2051 -> T' = 512 (two 256-key chunks per attention workgroup, two query blocks
+    per (utterance, head)), ragged lengths, default 12-layer model; two utterances are checked against the oracle."""
+    kw = base_kwargs()
+    ref, gpu = make_pair(kw, seed=21, style="trained")
+    mel = synth.synth_mel(6, 80, 2051, seed=21)
+    lens = torch.tensor([2051, 1999, 1500, 1027, 640, 2051])
+    out = run_gpu(gpu, mel, lens)
+    assert out.shape == (6, 6, 512, 256) and torch.isfinite(out).all()
+    idx = [0, 4]
+    with torch.no_grad():
+        want = ref(mel[idx], lens[idx])
+    assert (out[:, idx] - want).abs().max().item() < TOL["f16f8"]
+
