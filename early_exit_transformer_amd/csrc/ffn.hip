@@ -190,6 +190,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // CUs of an XCD stream the same weights out of the same L2 in lockstep): -4 % FFN time, but the fp32
   // summation order then depends on the tile index, i.e. on an utterance's position in the batch.  Off by
   // default: results are bit-identical under batch sharding.
+#ifndef EEC_SKEW
+#define EEC_SKEW 56
+#endif
 #ifndef EEC_WARM_SLOTS
 #define EEC_WARM_SLOTS 4  // slots before the end of a stage at which the consumers start the L2 warm-up
 #endif
@@ -204,6 +207,13 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   int tl_idx = 0;
 #endif
   TL_STAMP();  // 0: kernel entry
+#if EEC_SKEW > 0
+  // De-phase the workgroups that share an XCD (blockIdx % 8) by up to 3 x EEC_SKEW x 64 cycles (~5 us): all 32 CUs of
+  // an XCD otherwise walk the same weight stream in lockstep and hit the same L2 channels at the same time.  Unlike a
+  // rotated chunk order (EEC_FFN_ROT) this changes no arithmetic.  Measured: neutral on boxes that run the forward in
+  // 2.8 ms, -9 % on a box that ran it in 3.3 ms.
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(EEC_SKEW);
+#endif
   constexpr int RNP = NP == 8 ? 1 : NP;  // the f8 stream keeps only the hi fragments in the ring
   // Everything below is instantiated ONCE PER ROLE (the tag is a compile-time bool) and the role split is the
   // outermost branch: each role then carries only its own rings and accumulators through the stage loop
