@@ -176,6 +176,29 @@ def test_config_surface(over):
     assert (run_gpu(gpu, mel, lens) - want).abs().max().item() < TOL["f16x3"]
 
 
+@pytest.mark.parametrize("case", range(10))
+def test_random_configs_and_batches(case):
+    """Seeded random sweep over the supported configuration surface and ragged batches (the reference's own tests
+    hold no such cases; the oracle is the judge)."""
+    g = np.random.default_rng(1000 + case)
+    kw = base_kwargs(
+        n_enc_exits=int(g.integers(1, 4)), n_enc_layers=int(g.integers(1, 3)),
+        d_feed_forward=int(g.choice([96, 128, 320, 384, 512])), n_head=int(g.choice([4, 8])),
+        depthwise_kernel_size=int(g.choice([3, 9, 15, 31])), dec_voc_size=int(g.choice([32, 96, 256])),
+        features_length=int(g.choice([16, 48, 80])))
+    B, T = int(g.integers(1, 7)), int(g.integers(7, 700))
+    lens = g.integers(1, T + 1, size=B)
+    lens[int(g.integers(0, B))] = T  # the reference's mask needs max(lengths) == T
+    ref, gpu = make_pair(kw, seed=1000 + case)
+    mel, lt = synth.synth_mel(B, kw["features_length"], T, seed=case), torch.tensor(lens)
+    with torch.no_grad():
+        want = ref(mel, lt)
+    prec = ["f16f8", "f16x3"][case % 2]
+    got = run_gpu(gpu, mel, lt, prec)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < TOL[prec], (kw, B, T, lens.tolist())
+
+
 def test_full_conformer_encoder_taps_golden():
     """config 5 substitute: full_conformer._encoder_(src, lengths, n) (early_exit.py:719-737), fixture from the
     reference's own full_conformer."""
