@@ -162,14 +162,15 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
   {
     const int c = (threadIdx.x & 127) * 2, tg = threadIdx.x >> 7;  // 2 channels x frames [16 tg, 16 tg + 16)
     const int m0 = row0 + tg * kDwFrames;                           // first output row of this thread
-    float2 win[kDwWin];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));  // two adjacent channels: v_pk_fma_f32
+    f32x2 win[kDwWin];
 #pragma unroll
     for (int k = 0; k < kDwWin; ++k) {
       const h2 g = *(const h2*)(lds_g + (tg * kDwFrames + k) * kGLd + c * 2);
-      win[k] = make_float2((float)g[0], (float)g[1]);
+      win[k] = (f32x2){(float)g[0], (float)g[1]};
     }
-    const float2 bias = *(const float2*)(d.bfold + c);
-    float2 acc[kDwFrames];
+    const f32x2 bias = *(const f32x2*)(d.bfold + c);
+    f32x2 acc[kDwFrames];
 #pragma unroll
     for (int i = 0; i < kDwFrames; ++i) acc[i] = bias;
     // window rows are flattened rows m0-15 .. m0+30.  When the 16 output frames lie in one utterance
@@ -186,16 +187,13 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
         const int klo = b0 * Tq - first, khi = (b0 + 1) * Tq - 1 - first;
 #pragma unroll
         for (int k = 0; k < kDwWin; ++k)
-          if (k < klo || k > khi) win[k] = make_float2(0.f, 0.f);
+          if (k < klo || k > khi) win[k] = (f32x2){0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < kDwTaps; ++j) {
-        const float2 wv = *(const float2*)(lds_w + j * kD + c);
+        const f32x2 wv = *(const f32x2*)(lds_w + j * kD + c);
 #pragma unroll
-        for (int i = 0; i < kDwFrames; ++i) {
-          acc[i].x = fmaf(wv.x, win[i + j].x, acc[i].x);
-          acc[i].y = fmaf(wv.y, win[i + j].y, acc[i].y);
-        }
+        for (int i = 0; i < kDwFrames; ++i) acc[i] = __builtin_elementwise_fma(wv, win[i + j], acc[i]);
       }
     } else {
       // per output row i the valid window slots are [klo, khi]: same utterance as the output row
@@ -208,7 +206,7 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
       }
 #pragma unroll
       for (int j = 0; j < kDwTaps; ++j) {
-        const float2 wv = *(const float2*)(lds_w + j * kD + c);
+        const f32x2 wv = *(const f32x2*)(lds_w + j * kD + c);
 #pragma unroll
         for (int i = 0; i < kDwFrames; ++i) {
           const bool ok = (i + j) >= klo[i] && (i + j) <= khi[i];
