@@ -136,6 +136,7 @@ namespace {
 
 struct Workspace {
   float* x;
+  float* y;  // [(E-1)][M][256]: exit rows for the batched head launch when the caller passes no tap buffer
   half_t *mid_hi, *mid_lo, *q, *k, *vt, *p_hi, *p_lo, *g;
   int* enc_len;
   size_t bytes;
@@ -148,6 +149,7 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   a.base = base;
   Workspace w;
   w.x = a.take<float>(M * D);
+  w.y = a.take<float>((size_t)(c.n_exits > 1 ? c.n_exits - 1 : 0) * M * D);
   w.mid_hi = a.take<half_t>((size_t)B * T1 * D);
   w.mid_lo = a.take<half_t>((size_t)B * T1 * D);
   w.q = a.take<half_t>((size_t)B * Tp * D);
@@ -439,7 +441,9 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       return FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
                       L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap};
     };
-    float* y_scratch = (float*)ws.mid_hi;  // exit rows for the head when no tap buffer is given (the stem scratch is dead)
+    const bool batch_heads = out && c.n_exits <= kMaxHeadExits;  // all exit heads in ONE launch after the last layer
+    HeadBatchArgs hb{};
+    hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = c.n_exits;
     {
       ChainArgs ca{};
       ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
@@ -457,7 +461,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
       TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
       float* tap = nullptr;  // where the exit's encoder output goes besides x (x itself moves on to ffn1 of the next layer)
-      if (exit_layer) tap = taps_opt ? taps_opt + (size_t)e * M * D : ((out && !last) ? y_scratch : nullptr);
+      if (exit_layer) tap = taps_opt ? taps_opt + (size_t)e * M * D : ((out && !last) ? ws.y + (size_t)e * M * D : nullptr);
       ChainArgs ca{};
       ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
       ca.dw = DwArgs{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
@@ -469,10 +473,16 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       }
       TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, true, !last, false, st));
       if (exit_layer && out) {
-        HeadArgs h{last ? ws.x : tap, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
-        TIMED(KC_HEAD, launch_head(h, np_o, st));
+        const float* rows = last ? ws.x : tap;
+        if (batch_heads) {
+          hb.x[e] = rows, hb.wp[e] = enc->head_p[e], hb.bias[e] = enc->head_b[e];
+        } else {
+          HeadArgs h{rows, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+          TIMED(KC_HEAD, launch_head(h, np_o, st));
+        }
       }
     }
+    if (batch_heads) TIMED(KC_HEAD, launch_head_batch(hb, np_o, st));
     return finish_dbg();
   }
 

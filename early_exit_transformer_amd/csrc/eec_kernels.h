@@ -62,6 +62,18 @@ struct HeadArgs {  // out = log_softmax(x . W^T + b)
 };
 hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st);
 
+// All exit heads in ONE launch (north_star: "all exit logits come from one launch"): exit e reads its rows from
+// x[e] ([M][256] fp32: the exit taps, the last exit straight from the residual stream) and writes out + e*M*V.
+constexpr int kMaxHeadExits = 16;
+struct HeadBatchArgs {
+  const float* x[kMaxHeadExits];
+  const uint4* wp[kMaxHeadExits];
+  const float* bias[kMaxHeadExits];
+  float* out;  // [E][M][V]
+  int M, V, E;
+};
+hipError_t launch_head_batch(const HeadBatchArgs& a, int np, hipStream_t st);
+
 struct AttnArgs {
   const half_t *q, *k, *vt;
   const int* enc_len;  // [B] valid encoder frames (keys >= len are masked)

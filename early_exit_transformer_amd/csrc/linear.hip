@@ -251,14 +251,11 @@ hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipSt
 }
 
 // ---------------------------------------------------------------------------
-// Exit head.  V <= 256, V % 32 == 0.  Wave w owns vocabulary tile w (idle if 32w >= V); the
-// log-sum-exp of a frame is assembled from the 8 per-wave (max, sum) partials through LDS.
-constexpr int kHeadLds = kLinLds + 8 * 64 * 8;
+// Exit head.  V <= 256, V % 32 == 0.  Wave w owns vocabulary tile w of the GEMM (idle if 32w >= V).
+constexpr int kHeadLds = kLinLds;
 
 template <int NP>
-__global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2* stats = (float2*)(smem + kLinLds);  // [wave][frame] (max, sum exp(. - max))
+__device__ __forceinline__ void head_body(char* smem, const HeadArgs& a) {
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * kTileRows;
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
@@ -272,43 +269,38 @@ __global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
     acc_init_bias<2>(acc, a.bias + 32 * w);
     gemm_ring<NP, kD / 16, 1, true, kLPF>(acc, a_lane, kALd, kAPlane, wfrag_lane(a.wp, w), 0, r);
   }
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    float mx = -INFINITY, sm = 0.f;
-    if (active) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc[mt][0][i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sm += __expf(acc[mt][0][i] - mx);
-      sm += __shfl_xor(sm, 32, 64);
-    }
-    if (hh == 0) stats[w * 64 + mt * 32 + lane] = make_float2(mx, sm);
-  }
+  // logits -> fp32 exchange tile (over the dead activation planes) -> each wave finishes 8 whole frames: the
+  // log-sum-exp is a wave reduction and every output row leaves as one contiguous store (V * 4 bytes)
+  __syncthreads();  // every wave is done reading the planes
+  if (active) acc_swapped_to_etile(smem, acc);
   __syncthreads();
-  if (!active) return;
+  const int c0 = lane * 4;  // this lane's 4 vocabulary entries
+  const bool has = c0 < a.V;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
-    const int fr = mt * 32 + (lane & 31);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) mx = fmaxf(mx, stats[j * 64 + fr].x);
-    float sm = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float2 p = stats[j * 64 + fr];
-      sm += p.y * __expf(p.x - mx);  // inactive waves hold (-inf, 0): exp(-inf) * 0 = 0
-    }
+  for (int i = 0; i < 8; ++i) {
+    const int rl = w * 8 + i, row = row0 + rl;
+    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (has) v = *(const float4*)(smem + rl * kELd + c0 * 4);
+    const float mx = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    const float sm = wave_sum(has ? __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx) : 0.f);
     const float lse = mx + __logf(sm);
-    const int row = row0 + fr;
-    if (row < a.M) {
-      float* dst = a.out + (size_t)row * a.V + 32 * w + 4 * hh;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        *(float4*)(dst + 8 * g) = make_float4(acc[mt][0][4 * g + 0] - lse, acc[mt][0][4 * g + 1] - lse,
-                                              acc[mt][0][4 * g + 2] - lse, acc[mt][0][4 * g + 3] - lse);
-    }
+    if (has && row < a.M) *(float4*)(a.out + (size_t)row * a.V + c0) = make_float4(v.x - lse, v.y - lse, v.z - lse, v.w - lse);
   }
+}
+
+template <int NP>
+__global__ __launch_bounds__(kLinThreads, 2) void head_kernel(HeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  head_body<NP>(smem, a);
+}
+
+// blockIdx.y = exit: the per-exit pointers are picked out of the argument block with a wave-uniform index
+template <int NP>
+__global__ __launch_bounds__(kLinThreads, 2) void head_batch_kernel(HeadBatchArgs b) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int e = blockIdx.y;
+  const HeadArgs a{b.x[e], b.M, b.V, b.wp[e], b.bias[e], b.out + (size_t)e * b.M * b.V};
+  head_body<NP>(smem, a);
 }
 
 hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
@@ -317,6 +309,16 @@ hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
   hipError_t e = set_lds_once(k, kHeadLds, np == 3 ? d3 : d1);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kHeadLds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_head_batch(const HeadBatchArgs& a, int np, hipStream_t st) {
+  if (a.E < 1 || a.E > kMaxHeadExits) return hipErrorInvalidValue;
+  static bool d3 = false, d1 = false;
+  auto k = np == 3 ? head_batch_kernel<3> : head_batch_kernel<1>;
+  hipError_t e = set_lds_once(k, kHeadLds, np == 3 ? d3 : d1);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows, a.E), dim3(kLinThreads), kHeadLds, st, a);
   return hipGetLastError();
 }
 
