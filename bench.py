@@ -119,7 +119,7 @@ def main():
     roofline, kernel_ms = None, None
     if rank == 0:
         model.set_profiling(True)
-        run_steps(max(3, min(args.steps, 10)))
+        run_steps(max(3, min(args.steps, 10)), with_loss=False)  # forward only: no collective outside the timed region
         torch.cuda.synchronize()
         prof = model.read_profile()
         model.set_profiling(False)

@@ -7,6 +7,9 @@
 #include <vector>
 
 #include "../../include/eec.h"
+#include <cstdlib>
+#include <cstring>
+
 #include "eec_kernels.h"
 
 using namespace eec;
@@ -357,6 +360,17 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   hipStream_t st = (hipStream_t)stream;
   const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
+  // operand format per GEMM group of the production plan (all np_o; a diagnostic build can override them one by one)
+  int np_qkv = np_o, np_att = np_o, np_glu = np_o, np_front = np_o, np_head = np_o;
+#ifdef EEC_NP_EXPERIMENT
+  if (const char* ov = getenv("EEC_NP_OVERRIDE")) {  // e.g. "qkv=1,glu=1": error-budget experiments (tools/np_budget.py)
+    auto pick = [&](const char* key, int& dst) {
+      const char* p = strstr(ov, key);
+      if (p) dst = atoi(p + strlen(key));
+    };
+    pick("qkv=", np_qkv), pick("att=", np_att), pick("glu=", np_glu), pick("front=", np_front), pick("head=", np_head);
+  }
+#endif
   const int M = B * Tq, D = c.d_model, H = c.n_heads;
   int step = 0;
   auto done = [&](void) -> bool { return stop_after >= 0 && step > stop_after; };
@@ -449,17 +463,17 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
       ca.st[0] = stage1(enc->layers[0]);
       ca.qkv = qkv_args(enc->layers[0]);
-      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, false, true, false, st));
+      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_front, np_qkv, false, true, false, st));
     }
     for (int li = 0; li < n_layers; ++li) {
       const PackedLayer& L = enc->layers[li];
       const int e = li / c.layers_per_exit;
       const bool exit_layer = (li + 1) % c.layers_per_exit == 0, last = li + 1 == n_layers;
       AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
-      TIMED(KC_ATTN, launch_attention(at, np_o, st));
+      TIMED(KC_ATTN, launch_attention(at, np_att, st));
       ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
       GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
-      TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
+      TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_glu, st));
       float* tap = nullptr;  // where the exit's encoder output goes besides x (x itself moves on to ffn1 of the next layer)
       if (exit_layer) tap = taps_opt ? taps_opt + (size_t)e * M * D : ((out && !last) ? ws.y + (size_t)e * M * D : nullptr);
       ChainArgs ca{};
@@ -471,7 +485,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
         ca.st[1] = stage1(enc->layers[li + 1]);
         ca.qkv = qkv_args(enc->layers[li + 1]);
       }
-      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, true, !last, false, st));
+      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_front, np_qkv, true, !last, false, st));
       if (exit_layer && out) {
         const float* rows = last ? ws.x : tap;
         if (batch_heads) {
@@ -482,7 +496,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
         }
       }
     }
-    if (batch_heads) TIMED(KC_HEAD, launch_head_batch(hb, np_o, st));
+    if (batch_heads) TIMED(KC_HEAD, launch_head_batch(hb, np_head, st));
     return finish_dbg();
   }
 

@@ -112,7 +112,7 @@ struct ChainArgs {
   DwArgs dw;        // front
   ProjResArgs pw2;  // front (a_hi / a_lo unused)
 };
-hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_o, bool front, bool tail, bool relu, hipStream_t st);
+hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st);
 
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]

@@ -521,7 +521,7 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
 }
 
 // np: FFN format (1, 3, 8); np_o: format of the optional front / tail (1 or 3)
-hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_o, bool front, bool tail, bool relu, hipStream_t st) {
+hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st) {
   ChainArgs a = a_in;
   if (a.nstage < 1 || a.nstage > 2) return hipErrorInvalidValue;
   for (int i = 0; i < a.nstage; ++i)
@@ -532,7 +532,7 @@ hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_o, bool front,
     if (np == 3) return launch_chain_t<3, 1, 0, 0, 1>(a, st);
     return launch_chain_t<1, 1, 0, 0, 1>(a, st);
   }
-  const int f = front ? np_o : 0, q = tail ? np_o : 0;
+  const int f = front ? np_front : 0, q = tail ? np_tail : 0;
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
   if (np == NP_ && f == F_ && q == Q_)                                                                   \
     return a.nstage == 2 ? launch_chain_t<NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<NP_, 0, F_, Q_, 1>(a, st);
@@ -540,6 +540,9 @@ hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_o, bool front,
   EEC_CHAIN_CASE(3, 0, 0) EEC_CHAIN_CASE(3, 3, 0) EEC_CHAIN_CASE(3, 0, 3) EEC_CHAIN_CASE(3, 3, 3)
   EEC_CHAIN_CASE(1, 0, 0) EEC_CHAIN_CASE(1, 3, 0) EEC_CHAIN_CASE(1, 0, 3) EEC_CHAIN_CASE(1, 3, 3)
   EEC_CHAIN_CASE(1, 1, 0) EEC_CHAIN_CASE(1, 0, 1) EEC_CHAIN_CASE(1, 1, 1)
+#ifdef EEC_NP_EXPERIMENT  // diagnostic build: independent operand formats for the conv front and the in_proj tail
+  EEC_CHAIN_CASE(8, 1, 0) EEC_CHAIN_CASE(8, 0, 1) EEC_CHAIN_CASE(8, 1, 1) EEC_CHAIN_CASE(8, 1, 3) EEC_CHAIN_CASE(8, 3, 1)
+#endif
 #undef EEC_CHAIN_CASE
   return hipErrorInvalidValue;
 }
@@ -549,7 +552,7 @@ hipError_t launch_ffn(const FfnArgs& f, int np, hipStream_t st) {
   ChainArgs a{};
   a.x = f.x, a.M = f.M, a.F = f.F, a.nstage = 1;
   a.st[0] = FfnStage{f.ln_g, f.ln_b, f.w1p, f.b1, f.w2p, f.b2, f.fin_g, f.fin_b, f.w1f8, f.w2f8, f.res_scale, nullptr};
-  return launch_ffn_chain(a, np, 3, false, false, f.relu, st);
+  return launch_ffn_chain(a, np, 3, 3, false, false, f.relu, st);
 }
 
 }  // namespace eec
