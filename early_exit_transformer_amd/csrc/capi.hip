@@ -343,11 +343,13 @@ size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T) {
   return carve_ws(enc->cfg, B, T, nullptr).bytes;
 }
 
-int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
+// n_groups: exit groups to run (1 .. E); the production plan then ends after the last layer of group n_groups
+static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
                         float* out, float* taps_opt, void* workspace, size_t workspace_bytes, int stop_after,
-                        float* x_dbg_opt, void* stream) {
+                        float* x_dbg_opt, int n_groups, void* stream) {
   if (!enc || !mel || !lengths || !workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
-  if (!out && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "out is null");
+  if (!out && !taps_opt && !x_dbg_opt && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "no output buffer given");
+  if (n_groups < 1 || n_groups > enc->cfg.n_exits) return fail(EEC_ERR_BAD_ARG, "n_groups must be in 1 .. n_exits");
   if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
   if (B <= 0 || T < 7) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 7 (two k=3 s=2 convs)");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
@@ -403,7 +405,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
   if (c.arch == EEC_ARCH_LEGACY) {
     // Early_encoder: every key is valid (mask=None): overwrite the clamp(lengths/4) result with T'
     EEC_HIP(launch_fill_int(ws.enc_len, B, Tq, st));
-    for (int e = 0; e < c.n_exits; ++e) {
+    for (int e = 0; e < n_groups; ++e) {
       for (int l = 0; l < c.layers_per_exit; ++l) {
         const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
         {
@@ -443,7 +445,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
     // and only the two steps with cross-tile dependencies keep their own launch: attention (all keys of the
     // utterance) and out_proj + LN + pointwise-1 + GLU (whose output the depthwise conv reads with a +-15 frame
     // halo).  The sub-step hook (stop_after >= 0) uses the unfused plan below; both are parity-tested.
-    const int n_layers = c.n_exits * c.layers_per_exit;
+    const int n_layers = n_groups * c.layers_per_exit;
     auto qkv_args = [&](const PackedLayer& L) {
       return QkvArgs{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
     };
@@ -455,9 +457,9 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       return FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
                       L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap};
     };
-    const bool batch_heads = out && c.n_exits <= kMaxHeadExits;  // all exit heads in ONE launch after the last layer
+    const bool batch_heads = out && n_groups <= kMaxHeadExits;  // all exit heads in ONE launch after the last layer
     HeadBatchArgs hb{};
-    hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = c.n_exits;
+    hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = n_groups;
     {
       ChainArgs ca{};
       ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
@@ -500,7 +502,7 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
     return finish_dbg();
   }
 
-  for (int e = 0; e < c.n_exits; ++e) {
+  for (int e = 0; e < n_groups; ++e) {
     for (int l = 0; l < c.layers_per_exit; ++l) {
       const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
       {
@@ -551,6 +553,23 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
       EEC_HIP(hipMemcpyAsync(taps_opt + (size_t)e * M * D, ws.x, (size_t)M * D * 4, hipMemcpyDeviceToDevice, st));
   }
   return finish_dbg();
+}
+
+int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
+                        float* out, float* taps_opt, void* workspace, size_t workspace_bytes, int stop_after,
+                        float* x_dbg_opt, void* stream) {
+  if (!enc) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!out && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "out is null");
+  return forward_impl(enc, mel, lengths, B, T, precision, out, taps_opt, workspace, workspace_bytes, stop_after, x_dbg_opt,
+                      enc->cfg.n_exits, stream);
+}
+
+int eec_encoder_forward_prefix(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
+                               int n_groups, float* out_opt, float* taps_opt, float* x_out_opt, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  if (!enc) return fail(EEC_ERR_BAD_ARG, "null argument");
+  return forward_impl(enc, mel, lengths, B, T, precision, out_opt, taps_opt, workspace, workspace_bytes, -1, x_out_opt,
+                      n_groups, stream);
 }
 
 int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,

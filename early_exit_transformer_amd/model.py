@@ -140,7 +140,9 @@ class _HipEncoderMixin:
         return ws
 
     def _run_encoder(self, src: Tensor, lengths: Tensor, want_out: bool = True, want_taps: bool = False,
-                     stop_after: int = -1, want_x: bool = False):
+                     stop_after: int = -1, want_x: bool = False, n_groups: Optional[int] = None):
+        """``n_groups`` (1 .. E): stop after that many exit groups (eec_encoder_forward_prefix, production launch plan);
+        ``out`` / ``taps`` then hold only the exits that were run."""
         if not src.is_cuda:
             raise RuntimeError("the MI355X encoder runs on a HIP device only; move the model and inputs to "
                                "'cuda' (there is no CPU fallback -- the CPU reference lives in oracle/).")
@@ -160,18 +162,30 @@ class _HipEncoderMixin:
             src = src.contiguous().float()
             len_dev = lengths.to(device=dev, dtype=torch.int64).contiguous()
             E, D, V = self._cfg.n_exits, self._cfg.d_model, self._cfg.vocab
+            if n_groups is not None:
+                if stop_after >= 0:
+                    raise ValueError("n_groups and stop_after are exclusive")
+                if not 1 <= int(n_groups) <= E:
+                    raise ValueError(f"n_groups must be in 1 .. {E}")
+                E = int(n_groups)
             out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev) if want_out else None
             taps = torch.empty((E, B, Tq, D), dtype=torch.float32, device=dev) if want_taps else None
             xdbg = torch.empty((B, Tq, D), dtype=torch.float32, device=dev) if want_x else None
             ws = self._workspace(B, T, dev)
             ws_ptr = (ws.data_ptr() + 255) // 256 * 256
             stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = lib.eec_encoder_forward(
-                self._enc, src.data_ptr(), len_dev.data_ptr(), B, T, capi.PRECISIONS[self.precision],
-                out.data_ptr() if out is not None else None, taps.data_ptr() if taps is not None else None,
-                ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), stop_after,
-                xdbg.data_ptr() if xdbg is not None else None, C.c_void_p(stream))
-            capi.check(rc, "eec_encoder_forward")
+            ptr = lambda t: t.data_ptr() if t is not None else None  # noqa: E731
+            if n_groups is not None:
+                rc = lib.eec_encoder_forward_prefix(
+                    self._enc, src.data_ptr(), len_dev.data_ptr(), B, T, capi.PRECISIONS[self.precision], E,
+                    ptr(out), ptr(taps), ptr(xdbg), ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), C.c_void_p(stream))
+                capi.check(rc, "eec_encoder_forward_prefix")
+            else:
+                rc = lib.eec_encoder_forward(
+                    self._enc, src.data_ptr(), len_dev.data_ptr(), B, T, capi.PRECISIONS[self.precision],
+                    ptr(out), ptr(taps), ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()), stop_after, ptr(xdbg),
+                    C.c_void_p(stream))
+                capi.check(rc, "eec_encoder_forward")
             # src/len_dev must outlive the asynchronous launches on this stream
             src.record_stream(torch.cuda.current_stream(dev))
             len_dev.record_stream(torch.cuda.current_stream(dev))
@@ -199,6 +213,11 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
 
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
         return self._run_encoder(src, lengths)[0]
+
+    def forward_exits(self, src: Tensor, lengths: Tensor, n_exits: int) -> Tensor:
+        """Early exit (extension; the reference's forward always runs every group): log-probs of the first
+        ``n_exits`` exits only, [n_exits, B, T', V], at n_exits / E of the cost of ``forward``."""
+        return self._run_encoder(src, lengths, n_groups=n_exits)[0]
 
     def greedy_decode(self, enc_out: Tensor, blank: int = 0) -> List[List[List[int]]]:
         """Batched GreedyCTCDecoder (util/beam_infer.py:9-24) over every exit and utterance."""
@@ -280,9 +299,8 @@ class full_conformer(_HipEncoderMixin, nn.Module):
 
     def _encoder_(self, src: Tensor, lengths: Tensor, layer_n: int) -> Tensor:
         """Pre-head activations after ``layer_n`` exit groups, [B, T', D] (early_exit.py:719-737)."""
-        L = self._cfg.layers_per_exit
         n = int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits  # reference loop
-        return self._run_encoder(src, lengths, want_out=False, stop_after=4 * L * n, want_x=True)[2]
+        return self._run_encoder(src, lengths, want_out=False, want_x=True, n_groups=n)[2]
 
     def _decode_one(self, trg: Tensor, enc: Tensor, idx: int) -> Tensor:
         sz = trg.size(1)

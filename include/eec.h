@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 3
+#define EEC_ABI_VERSION 4
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -136,6 +136,17 @@ size_t eec_encoder_workspace_bytes(const eec_encoder* enc, int B, int T);
 int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T,
                         int precision, float* out, float* taps_opt, void* workspace, size_t workspace_bytes,
                         int stop_after, float* x_dbg_opt, void* stream);
+
+/* Early exit: the same forward, stopped after the first n_groups exit groups (1 .. E) -- what the reference does with
+ * full_conformer._encoder_(src, lengths, layer_n) (early_exit.py:719-737: the loop breaks after layer_n groups) and what
+ * an early-exit deployment runs when it decodes from exit n_groups.  Production launch plan; cost is n_groups / E of a
+ * full forward.
+ *   out_opt   [n_groups, B, T', V] log-probs of the exits that were run, or NULL
+ *   taps_opt  [n_groups, B, T', D] or NULL          x_out_opt [B, T', D]: encoder output after group n_groups, or NULL
+ * At least one of the three must be given. */
+int eec_encoder_forward_prefix(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
+                               int n_groups, float* out_opt, float* taps_opt, float* x_out_opt, void* workspace,
+                               size_t workspace_bytes, void* stream);
 
 /* Measurement hook (no reference counterpart; the reference has no profiler hooks):
  * when enabled, every kernel launch of eec_encoder_forward is bracketed by hipEventRecord on the

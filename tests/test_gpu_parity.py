@@ -40,7 +40,7 @@ def run_gpu(model, mel, lens, prec="f16f8"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 3
+    assert lib.eec_abi_version() == 4
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
@@ -197,6 +197,27 @@ def test_random_configs_and_batches(case):
     got = run_gpu(gpu, mel, lt, prec)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < TOL[prec], (kw, B, T, lens.tolist())
+
+
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3"])
+def test_early_exit_prefix_equals_full_forward(prec):
+    """eec_encoder_forward_prefix (run only the first n exit groups) returns bit for bit what the full forward
+    returns for those exits, and its final residual stream is exit n's tap."""
+    kw = base_kwargs(n_enc_exits=4, n_enc_layers=2, d_feed_forward=384)
+    ref, gpu = make_pair(kw, seed=31)
+    mel, lens = synth.synth_mel(3, 80, 331, seed=31), torch.tensor([331, 200, 64])
+    gpu.precision = prec
+    with torch.no_grad():
+        full, taps, _ = gpu._run_encoder(mel.cuda(), lens, want_taps=True)
+        for n in (1, 2, 4):
+            out_n, taps_n, x_n = gpu._run_encoder(mel.cuda(), lens, want_taps=True, want_x=True, n_groups=n)
+            assert out_n.shape[0] == n and torch.equal(out_n, full[:n]) and torch.equal(taps_n, taps[:n])
+            assert torch.equal(x_n, taps[n - 1])
+        assert torch.equal(gpu.forward_exits(mel.cuda(), lens, 3), full[:3])
+        want = ref(mel, lens)
+    assert (full.cpu() - want).abs().max().item() < TOL[prec]
+    with pytest.raises(ValueError):
+        gpu._run_encoder(mel.cuda(), lens, n_groups=5)
 
 
 def test_full_conformer_encoder_taps_golden():
