@@ -1,7 +1,11 @@
-// Fused Conformer feed-forward half-step (torchaudio _FeedForwardModule
-// + the 0.5*y + x residual of ConformerLayer; a8 for the optional final LayerNorm):
+// The row-tile chain kernel.  Its core is the fused Conformer feed-forward half-step (SURVEY 8a row a5,
+// torchaudio _FeedForwardModule + the 0.5*y + x residual of ConformerLayer; a8 for the optional final LayerNorm):
 //
 //     x <- [LN_final]( 0.5 * ( W2 . silu( W1 . LN(x) + b1 ) + b2 ) + x )
+//
+// of which one launch runs one or two, optionally preceded by the conv-module tail (depthwise + pointwise-2, a7) and
+// followed by the next half-layer's attention in_proj (a6) -- everything between two cross-tile dependencies of the
+// layer stack (see ffn_chain_kernel below and DESIGN.md section 5).
 //
 // One 512-thread workgroup owns 64 rows of x; the [64, F] hidden activation never leaves the CU.
 // F is walked in chunks of 128 hidden units.  The 8 waves are specialised (one wave of each kind
@@ -92,12 +96,7 @@ extern "C" int eec_debug_ksteps(unsigned long long* out) {
 #define TL_STAMP()
 #endif
 
-// L2 warm-up: one dword per 128-byte line, lane l -> line first_line + l of [base, base + 128 * n_lines).
-// The value only feeds a sink that keeps the load alive.
-__device__ __forceinline__ unsigned touch_lines(const void* base, size_t first_line, size_t n_lines) {
-  const size_t ln = first_line + lane_id();
-  return ln < n_lines ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
-}
+// L2 warm-up: one dword per 128-byte line; the value only feeds a sink that keeps the load alive.
 // instruction j (0 or 1) of this wave's part of the workgroup's 1/32 share of an array (the workgroups of an
 // XCD -- blockIdx % 8 -- share one L2; a share is at most 2 x 64 lines per wave for the matrices used here)
 __device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, int wl, int j, int lane = lane_id()) {
