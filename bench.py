@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Extra objects:
   cpu_baseline the CPU oracle (oracle/conformer_ref.py, a port of the reference path) timed on
                this box's host cores on a bounded sample of the same workload (rank 0, N=1 only)
   modes        the same step in the faster, lower-precision operand modes (not the headline value)
+  secondary_shapes  forward-only at SURVEY 8d's secondary shapes: ragged lengths, T=2051 (T'=512)
 """
 import argparse
 import json
@@ -189,6 +190,34 @@ def main():
                            "frac_of_mfma_peak": round(flop_fwd * args.steps / d / MFMA_PEAK_FLOPS, 4)}
         model.precision = args.precision
 
+    # ---- secondary shapes: forward-only, same model; reported, never the headline ----
+    secondary = {}
+    if rank == 0 and world == 1 and not args.no_modes:
+        def timed_forward(mel_s, len_s, n):
+            with torch.no_grad():
+                for _ in range(3):
+                    model(mel_s, len_s)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n):
+                    model(mel_s, len_s)
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n
+        n_sec = max(5, args.steps // 2)
+        g = torch.Generator().manual_seed(1)
+        ragged = torch.randint(T // 2, T + 1, (B,), generator=g, dtype=torch.int64)
+        ragged[0] = T  # the reference needs max(lengths) == T
+        d = timed_forward(mel, ragged, n_sec)
+        secondary["ragged_lengths"] = {"shape": f"B={B}, T={T}, lengths uniform in [T/2, T] (one == T)",
+                                       "value": round(B * T / d, 1), "ms_per_step": round(d * 1e3, 4),
+                                       "note": "padded frames are computed like the reference computes them; only keys are masked"}
+        B2, T2 = max(B // 2, 1), 2 * T - 3  # T' doubles, B halves: the same number of encoder frames
+        mel2 = synth.synth_mel(B2, CFG["features_length"], T2, seed=7).to(dev)
+        d = timed_forward(mel2, torch.full((B2,), T2, dtype=torch.int64), n_sec)
+        secondary["long_utterances"] = {"shape": f"B={B2}, T={T2} -> T'={(((T2 - 3) // 2 + 1) - 3) // 2 + 1}",
+                                        "value": round(B2 * T2 / d, 1), "ms_per_step": round(d * 1e3, 4)}
+        del mel2
+
     # ---- CPU baseline: the oracle on the host cores, bounded sample ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -227,7 +256,7 @@ def main():
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
-            "modes": modes,
+            "modes": modes, "secondary_shapes": secondary,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
