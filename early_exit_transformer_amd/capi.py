@@ -60,7 +60,8 @@ class EecParams(C.Structure):
 EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
            "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy",
-           "eec_encoder_forward_prefix"]
+           "eec_encoder_forward_prefix", "eec_encoder_group_workspace_bytes", "eec_encoder_group_forward",
+           "eec_encoder_head_forward"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -90,6 +91,11 @@ def load() -> C.CDLL:
                                         C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
     lib.eec_encoder_forward_prefix.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_encoder_group_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.eec_encoder_group_workspace_bytes.restype = C.c_size_t
+    lib.eec_encoder_group_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_encoder_head_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.eec_greedy_ctc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
     lib.eec_ctc_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

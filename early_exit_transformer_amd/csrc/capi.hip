@@ -70,6 +70,7 @@ struct eec_encoder {
   eec_config cfg;
   Arena arena;
   bool packed = false;
+  bool has_stem = false, has_heads = false;  // eec_encoder_pack may be given layers only (building-block use)
   // optional per-kernel-class timing with HIP events on the launch stream (bench/roofline only)
   bool profiling = false;
   std::vector<hipEvent_t> ev;       // pairs: start, stop
@@ -225,7 +226,8 @@ void eec_encoder_destroy(eec_encoder* enc) {
 }
 
 int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
-  if (!enc || !p || !p->layers || !p->head_w || !p->head_b) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!enc || !p || !p->layers) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if ((p->head_w == nullptr) != (p->head_b == nullptr)) return fail(EEC_ERR_BAD_ARG, "head_w and head_b go together");
   if (enc->cfg.arch != EEC_ARCH_CONFORMER) return fail(EEC_ERR_BAD_ARG, "use eec_encoder_pack_legacy for EEC_ARCH_LEGACY");
   hipStream_t st = (hipStream_t)stream;
   const eec_config& c = enc->cfg;
@@ -273,15 +275,21 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.final_ln_w, s.final_ln_w, D));
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
   }
-  EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
-  EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
-  EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
-  EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
-  EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
-  for (int e = 0; e < c.n_exits; ++e) {
-    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
-    EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+  enc->has_stem = p->sub0_w && p->sub0_b && p->sub1_w && p->sub1_b && p->pe;
+  if (enc->has_stem) {
+    EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
+    EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+    EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
+    EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
+    EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
   }
+  enc->has_heads = p->head_w != nullptr;
+  if (enc->has_heads)
+    for (int e = 0; e < c.n_exits; ++e) {
+      if (!p->head_w[e] || !p->head_b[e]) return fail(EEC_ERR_BAD_ARG, "null head parameter");
+      EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
+      EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+    }
   enc->packed = true;
   return 0;
 }
@@ -325,15 +333,21 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
     EEC_HIP(cp(L.final_ln_w, p->group_ln_w[e], D));
     EEC_HIP(cp(L.final_ln_b, p->group_ln_b[e], D));
   }
-  EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
-  EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
-  EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
-  EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
-  EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
-  for (int e = 0; e < c.n_exits; ++e) {
-    EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
-    EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+  enc->has_stem = p->sub0_w && p->sub0_b && p->sub1_w && p->sub1_b && p->pe;
+  if (enc->has_stem) {
+    EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
+    EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+    EEC_HIP(launch_pack_conv_jci(p->sub1_w, D, D, enc->sub_w2p, st));
+    EEC_HIP(cp(enc->sub_b2, p->sub1_b, D));
+    EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
   }
+  enc->has_heads = p->head_w != nullptr;
+  if (enc->has_heads)
+    for (int e = 0; e < c.n_exits; ++e) {
+      if (!p->head_w[e] || !p->head_b[e]) return fail(EEC_ERR_BAD_ARG, "null head parameter");
+      EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
+      EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
+    }
   enc->packed = true;
   return 0;
 }
@@ -350,6 +364,8 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   if (!enc || !mel || !lengths || !workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (!out && !taps_opt && !x_dbg_opt && stop_after < 0) return fail(EEC_ERR_BAD_ARG, "no output buffer given");
   if (n_groups < 1 || n_groups > enc->cfg.n_exits) return fail(EEC_ERR_BAD_ARG, "n_groups must be in 1 .. n_exits");
+  if (enc->packed && enc->cfg.arch == EEC_ARCH_CONFORMER && (!enc->has_stem || (out && !enc->has_heads)))
+    return fail(EEC_ERR_NOT_PACKED, "this encoder was packed without stem / head parameters");
   if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
   if (B <= 0 || T < 7) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 7 (two k=3 s=2 convs)");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
@@ -570,6 +586,101 @@ int eec_encoder_forward_prefix(eec_encoder* enc, const float* mel, const int64_t
   if (!enc) return fail(EEC_ERR_BAD_ARG, "null argument");
   return forward_impl(enc, mel, lengths, B, T, precision, out_opt, taps_opt, workspace, workspace_bytes, -1, x_out_opt,
                       n_groups, stream);
+}
+
+// ---------------------------------------------------------------------------
+// Building blocks: one exit group / one head on caller-owned rows.  They let a host compose the reference's
+// other encoder topologies (Splitformer early_exit.py:227-364: parallel down-sampled branches) out of the same
+// kernels; Early_conformer itself goes through eec_encoder_forward.
+struct GroupWs {
+  half_t *q, *k, *vt, *p_hi, *p_lo, *g;
+  size_t bytes;
+};
+static GroupWs carve_group_ws(const eec_config& c, int B, int Tq, char* base) {
+  const int Tp = (Tq + 31) / 32 * 32;
+  const size_t M = (size_t)B * Tq, D = c.d_model;
+  Arena a;
+  a.base = base;
+  GroupWs w;
+  w.q = a.take<half_t>((size_t)B * Tp * D);
+  w.k = a.take<half_t>((size_t)B * Tp * D);
+  w.vt = a.take<half_t>((size_t)B * Tp * D);
+  w.p_hi = a.take<half_t>(M * D);
+  w.p_lo = a.take<half_t>(M * D);
+  w.g = a.take<half_t>(M * D);
+  w.bytes = align_up(a.off);
+  return w;
+}
+
+size_t eec_encoder_group_workspace_bytes(const eec_encoder* enc, int B, int Tq) {
+  if (!enc || B <= 0 || Tq <= 0) return 0;
+  return carve_group_ws(enc->cfg, B, Tq, nullptr).bytes;
+}
+
+int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32_t* key_len, int B, int Tq, int precision,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+  if (!enc || !x || !key_len || !workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
+  const eec_config& c = enc->cfg;
+  if (c.arch != EEC_ARCH_CONFORMER) return fail(EEC_ERR_UNSUPPORTED, "group forward is built for EEC_ARCH_CONFORMER");
+  if (group < 0 || group >= c.n_exits) return fail(EEC_ERR_BAD_ARG, "group out of range");
+  if (B <= 0 || Tq <= 0) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T' > 0");
+  if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
+  if (((uintptr_t)workspace & 255) != 0) return fail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  const GroupWs ws = carve_group_ws(c, B, Tq, (char*)workspace);
+  if (workspace_bytes < ws.bytes) return fail(EEC_ERR_WORKSPACE, "workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
+  const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
+  const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
+  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
+  auto qkv_args = [&](const PackedLayer& L) {
+    return QkvArgs{x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+  };
+  auto stage1 = [&](const PackedLayer& L) {
+    return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
+                    L.ffn1_w1f8, L.ffn1_w2f8, 0.5f, nullptr};
+  };
+  const int l0 = group * c.layers_per_exit, l1 = l0 + c.layers_per_exit;
+  {
+    ChainArgs ca{};
+    ca.x = x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
+    ca.st[0] = stage1(enc->layers[l0]);
+    ca.qkv = qkv_args(enc->layers[l0]);
+    TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, np_o, false, true, false, st));
+  }
+  for (int li = l0; li < l1; ++li) {
+    const PackedLayer& L = enc->layers[li];
+    const bool last = li + 1 == l1;
+    AttnArgs at{ws.q, ws.k, ws.vt, key_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+    TIMED(KC_ATTN, launch_attention(at, np_o, st));
+    ProjResArgs pr{x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+    GluArgs ga{x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
+    TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
+    ChainArgs ca{};
+    ca.x = x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
+    ca.dw = DwArgs{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
+    ca.pw2 = ProjResArgs{x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+    ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
+                        L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, nullptr};
+    if (!last) {
+      ca.st[1] = stage1(enc->layers[li + 1]);
+      ca.qkv = qkv_args(enc->layers[li + 1]);
+    }
+    TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, np_o, true, !last, false, st));
+  }
+  return 0;
+}
+
+int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, float* out, int precision, void* stream) {
+  if (!enc || !x || !out) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!enc->packed || !enc->has_heads) return fail(EEC_ERR_NOT_PACKED, "no packed head parameters");
+  if (exit < 0 || exit >= enc->cfg.n_exits || M <= 0) return fail(EEC_ERR_BAD_ARG, "exit / M out of range");
+  if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
+  HeadArgs h{x, M, enc->cfg.vocab, enc->head_p[exit], enc->head_b[exit], out};
+  hipStream_t st = (hipStream_t)stream;
+  TIMED(KC_HEAD, launch_head(h, precision == EEC_PREC_F16 ? 1 : 3, st));
+  return 0;
 }
 
 int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,

@@ -48,6 +48,17 @@ class Conv1dSubampling(nn.Module):
             nn.Conv1d(out_channels, out_channels, kernel_size=3, stride=2, padding=0))
 
 
+def _layer_params(ptr, prefix: str, n_groups: int, n_layers: int):
+    """HOST array of EecLayerParams for ``{prefix}.{g}.conformer_layers.{l}.*`` (group-major)."""
+    layers = (capi.EecLayerParams * (n_groups * n_layers))()
+    for g in range(n_groups):
+        for l in range(n_layers):
+            lp = layers[g * n_layers + l]
+            for field, suffix in capi.LAYER_KEYS.items():
+                setattr(lp, field, ptr(f"{prefix}.{g}.conformer_layers.{l}.{suffix}"))
+    return layers
+
+
 class _HipEncoderMixin:
     """Owns the libeec encoder handle, the packed-weight cache and the workspace."""
 
@@ -100,12 +111,7 @@ class _HipEncoderMixin:
 
     def _pack(self, lib, device, sd, ptr) -> None:
         E, L = self._cfg.n_exits, self._cfg.layers_per_exit
-        layers = (capi.EecLayerParams * (E * L))()
-        for e in range(E):
-            for l in range(L):
-                lp = layers[e * L + l]
-                for field, suffix in capi.LAYER_KEYS.items():
-                    setattr(lp, field, ptr(f"conformer.{e}.conformer_layers.{l}.{suffix}"))
+        layers = _layer_params(ptr, "conformer", E, L)
         hw = (C.c_void_p * E)(*[ptr(f"{self._head_attr}.{e}.weight") for e in range(E)])
         hb = (C.c_void_p * E)(*[ptr(f"{self._head_attr}.{e}.bias") for e in range(E)])
         params = capi.EecParams(ptr("conv_subsample.sequential.0.weight"), ptr("conv_subsample.sequential.0.bias"),
@@ -225,6 +231,124 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         tokens, counts = greedy_ctc(enc_out.reshape(E * B, Tq, V), blank)
         tokens, counts = tokens.cpu(), counts.cpu()
         return [[tokens[e * B + b, : counts[e * B + b]].tolist() for b in range(B)] for e in range(E)]
+
+
+class _TimeResample(nn.Module):
+    """Parameterless stand-ins that keep the reference's module tree (Downsampling / Upsampling, early_exit.py:95-114)."""
+
+    def __init__(self, factor: int):
+        super().__init__()
+        self.factor = factor
+
+
+class Splitformer(Early_conformer):
+    """Drop-in for the reference's ``Splitformer`` (early_exit.py:227-364): Early_conformer plus,
+    at the first and the last exit, a one-layer Conformer on the 2x time-down-sampled input of that exit group, added
+    back (nearest-neighbour up-sampled) before the head.  Same constructor kwargs, ``forward(src, lengths)`` and
+    state_dict names.  Every Conformer group and every head runs in libeec (eec_encoder_group_forward /
+    eec_encoder_head_forward, the production chain-kernel plan); the strided slice, the repeat and the add that glue the
+    branch in are three torch ops on [B, T', 256] tensors.  Reference quirks kept: the branch's key lengths are
+    ``clamp((mel_lengths + pad) / 2, max=T'/2)`` (:324-331) and ``index // (n_enc_exits - 1)`` picks the branch."""
+
+    factor = 2
+
+    def __init__(self, src_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head, max_len,
+                 d_feed_forward, n_enc_layers, features_length, drop_prob, depthwise_kernel_size, device=None):
+        if n_enc_exits < 2:
+            raise ValueError("Splitformer needs n_enc_exits >= 2 (the reference divides by n_enc_exits - 1)")
+        super().__init__(src_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head, max_len,
+                         d_feed_forward, n_enc_layers, features_length, drop_prob, depthwise_kernel_size, device)
+        self.downsampling = nn.ModuleList([_TimeResample(self.factor) for _ in range(2)])
+        self.upsampling = nn.ModuleList([_TimeResample(self.factor) for _ in range(2)])
+        self.conformer_parallel = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_feed_forward, num_layers=1,
+                      depthwise_conv_kernel_size=depthwise_kernel_size, dropout=drop_prob) for _ in range(2)])
+        # second libeec handle: the two one-layer branch groups, packed without stem and heads
+        self._par_cfg = capi.EecConfig(d_model, n_head, d_feed_forward, depthwise_kernel_size, 2, 1, features_length,
+                                       dec_voc_size, max_len, capi.ARCH_CONFORMER)
+        self._par_enc = None
+        self._par_key = None
+        self._gws: Dict[Tuple[int, int, int], Tensor] = {}
+
+    def __del__(self):
+        enc = getattr(self, "_par_enc", None)
+        if enc is not None:
+            try:
+                capi.load().eec_encoder_destroy(enc)
+            except Exception:
+                pass
+        super().__del__()
+
+    def _ensure_branch_packed(self, device: torch.device) -> None:
+        tensors = list(self.conformer_parallel.parameters()) + list(self.conformer_parallel.buffers())
+        key = (device, tuple(t._version for t in tensors), tuple(t.data_ptr() for t in tensors))
+        if self._par_enc is not None and key == self._par_key:
+            return
+        lib = capi.load()
+        if self._par_enc is None:
+            h = C.c_void_p()
+            capi.check(lib.eec_encoder_create(C.byref(self._par_cfg), C.byref(h)), "eec_encoder_create")
+            self._par_enc = h
+        sd = dict(self.state_dict(keep_vars=True))
+
+        def ptr(name: str) -> int:
+            t = sd[name]
+            if t.device != device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {name} must be a contiguous fp32 tensor on {device}")
+            return t.data_ptr()
+
+        params = capi.EecParams(None, None, None, None, None, _layer_params(ptr, "conformer_parallel", 2, 1), None, None)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        capi.check(lib.eec_encoder_pack(self._par_enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
+        self._par_key = key
+
+    def _group(self, enc_handle, group: int, x: Tensor, key_len: Tensor) -> None:
+        """x [B, T', D] fp32 contiguous, in place; key_len [B] int32 on the device."""
+        lib, dev = capi.load(), x.device
+        B, Tq, _ = x.shape
+        k = (B, Tq, dev.index or 0)
+        ws = self._gws.get(k)
+        if ws is None:
+            if len(self._gws) > 4:
+                self._gws.clear()
+            ws = torch.empty(lib.eec_encoder_group_workspace_bytes(enc_handle, B, Tq) + 256, dtype=torch.uint8, device=dev)
+            self._gws[k] = ws
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.eec_encoder_group_forward(enc_handle, group, x.data_ptr(), key_len.data_ptr(), B, Tq,
+                                           capi.PRECISIONS[self.precision], ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
+                                           C.c_void_p(stream))
+        capi.check(rc, "eec_encoder_group_forward")
+
+    def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        # stem (+ PE) through the monolithic entry's first sub-step; also validates src and packs the main handle
+        x = self._run_encoder(src, lengths, want_out=False, stop_after=0, want_x=True)[2]
+        dev = x.device
+        with torch.cuda.device(dev):
+            self._ensure_branch_packed(dev)
+            lib = capi.load()
+            B, Tq, D = x.shape
+            E, V = self._cfg.n_exits, self._cfg.vocab
+            mel_len = lengths.to(device=dev, dtype=torch.int64)
+            base = torch.clamp(mel_len / 4, max=Tq).to(torch.int32)
+            out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for index in range(E):
+                branch = index in (0, E - 1)
+                side = x.clone() if branch else None  # the group's INPUT feeds the branch; the group runs in place
+                self._group(self._enc, index, x, base)
+                if branch:
+                    pad = (-Tq) % self.factor
+                    if pad:
+                        side = torch.cat((side, side.new_zeros(B, pad, D)), dim=1)
+                    side = side[:, :: self.factor, :].contiguous()
+                    side_len = torch.clamp((mel_len + pad) / self.factor, max=side.size(1)).to(torch.int32)
+                    self._group(self._par_enc, index // (E - 1), side, side_len)
+                    x = x + torch.repeat_interleave(side, self.factor, dim=1)[:, :Tq, :]
+                rc = lib.eec_encoder_head_forward(self._enc, index, x.data_ptr(), B * Tq, out[index].data_ptr(),
+                                                  capi.PRECISIONS[self.precision], C.c_void_p(stream))
+                capi.check(rc, "eec_encoder_head_forward")
+        return out
 
 
 def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 4
+#define EEC_ABI_VERSION 5
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -147,6 +147,19 @@ int eec_encoder_forward(eec_encoder* enc, const float* mel, const int64_t* lengt
 int eec_encoder_forward_prefix(eec_encoder* enc, const float* mel, const int64_t* lengths, int B, int T, int precision,
                                int n_groups, float* out_opt, float* taps_opt, float* x_out_opt, void* workspace,
                                size_t workspace_bytes, void* stream);
+
+/* Building blocks for the reference's other encoder topologies built from the same Conformer groups (Splitformer,
+ * early_exit.py:227-364: down-sampled parallel branches added to the main path at the first and last exit).
+ * eec_encoder_pack may be called with the stem (sub0_w .. pe) and / or the heads (head_w, head_b) left NULL for an
+ * encoder that is used through these entry points only.
+ *   eec_encoder_group_forward: x [B, T', D] fp32, in place, through the layers_per_exit Conformer layers of `group`
+ *       (= one torchaudio Conformer.forward(x, lengths), early_exit.py:603-615,627); key_len [B] int32 on the device:
+ *       keys >= key_len[b] are masked (the caller applies the reference's length rule); production launch plan.
+ *   eec_encoder_head_forward:  out [M, V] = log_softmax(x [M, D] . W_exit^T + b_exit)   (early_exit.py:629-631). */
+size_t eec_encoder_group_workspace_bytes(const eec_encoder* enc, int B, int Tq);
+int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32_t* key_len, int B, int Tq, int precision,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, float* out, int precision, void* stream);
 
 /* Measurement hook (no reference counterpart; the reference has no profiler hooks):
  * when enabled, every kernel launch of eec_encoder_forward is bracketed by hipEventRecord on the

@@ -215,6 +215,49 @@ class EarlyConformerRef(nn.Module):
         return (out, torch.stack(taps)) if return_taps else out
 
 
+class SplitformerRef(EarlyConformerRef):
+    """Restatement of Splitformer (early_exit.py:227-364): Early_conformer plus, at the FIRST and the LAST exit, a
+    one-layer Conformer that runs on the 2x time-down-sampled input of that exit group and is added back
+    (nearest-neighbour up-sampled) to the group's output before the head.  Reference quirks kept on purpose:
+    the branch's key lengths come from the MEL lengths, ``clamp((lengths + pad) / 2, max=T'/2)`` (:324-331), not
+    from the encoder lengths; ``index // (n_enc_exits - 1)`` picks the branch (:320), so n_enc_exits >= 2."""
+
+    factor = 2
+
+    def __init__(self, *args, **kw):
+        super().__init__(*args, **kw)
+        first = self.conformer[0].conformer_layers[0]
+        d_model, n_head = first.self_attn.embed_dim, first.self_attn.num_heads
+        d_ff = first.ffn1.sequential[1].out_features
+        dw = first.conv_module.sequential[2].kernel_size[0]
+        p = first.ffn1.sequential[3].p
+        self.conformer_parallel = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_ff, num_layers=1,
+                      depthwise_conv_kernel_size=dw, dropout=p) for _ in range(2)])
+
+    def forward(self, src: Tensor, lengths: Tensor) -> Tensor:  # type: ignore[override]
+        enc = self.stem(src)
+        base = encoder_lengths(lengths, enc.size(1))
+        outs: List[Tensor] = []
+        last = self.n_enc_exits - 1
+        for index, (head, group) in enumerate(zip(self.linears, self.conformer)):
+            side = enc  # the group's INPUT feeds the parallel branch
+            enc, _ = group(enc, base)
+            if index in (0, last):
+                pad = (-side.size(1)) % self.factor
+                if pad:
+                    side = torch.cat((side, side.new_zeros(side.size(0), pad, side.size(2))), dim=1)
+                side = side[:, :: self.factor, :]
+                side_len = torch.clamp((lengths + pad) / self.factor, max=side.size(1)).to(torch.int)
+                side, _ = self.conformer_parallel[index // last](side, side_len)
+                side = torch.repeat_interleave(side, self.factor, dim=1)
+                if pad:
+                    side = side[:, :-pad, :]
+                enc = enc + side
+            outs.append(F.log_softmax(head(enc), dim=2).unsqueeze(0))
+        return torch.cat(outs)
+
+
 def trace_substeps(model: "EarlyConformerRef", src: Tensor, lengths: Tensor) -> List[Tensor]:
     """Residual stream [B, T', D] after the stem and after every sub-step of every layer
     (ffn1, attention, conv, ffn2+final LN) -- the checkpoints ``eec_encoder_forward(stop_after=k)``

@@ -41,6 +41,33 @@ def test_oracle_equals_reference_class_body():
 
 
 @pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the build container")
+def test_splitformer_oracle_equals_reference_class_body():
+    """the reference's Splitformer (early_exit.py:227-364), imported unmodified, equals
+    oracle.SplitformerRef bit for bit -- odd T' (the branch zero-pads one frame) and even T', ragged lengths."""
+    ee = _import_reference()
+    kw = base_kwargs(n_enc_exits=3, n_enc_layers=1, d_feed_forward=256, depthwise_kernel_size=15, dec_voc_size=64)
+    ref, mine = ee.Splitformer(**kw).eval(), R.SplitformerRef(**kw).eval()
+    assert sorted(ref.state_dict().keys()) == sorted(mine.state_dict().keys())
+    sd = synth.synth_state_dict(ref.state_dict(), seed=5, style="trained")
+    ref.load_state_dict(sd, strict=True)
+    mine.load_state_dict(sd, strict=True)
+    for T, lens in ((203, [203, 150, 99]), (201, [201, 64, 201]), (410, [410, 100, 30])):
+        mel, lt = synth.synth_mel(3, 80, T, seed=5), torch.tensor(lens)
+        with torch.no_grad():
+            assert torch.equal(ref(mel, lt), mine(mel, lt))
+
+
+def test_splitformer_oracle_reproduces_golden():
+    z, kw = load_golden("splitformer_small")
+    model = R.SplitformerRef(**kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=int(z["seed"]), style="trained"), strict=True)
+    for i, (B, T, lens) in enumerate(eval(str(z["cases"]))):
+        with torch.no_grad():
+            out = model(synth.synth_mel(B, 80, T, seed=int(z["seed"]) + i), torch.tensor(lens))
+        assert torch.allclose(out, torch.from_numpy(z[f"logp{i}"]), atol=2e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the build container")
 def test_reference_legacy_attention_matches_torch_sdpa():
     """SURVEY 8a row a14: the legacy models/layers attention (importable as-is) is softmax(qk^T/sqrt(d))v;
     this is the un-masked special case of what the attention kernel computes."""
