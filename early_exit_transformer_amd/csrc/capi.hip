@@ -70,7 +70,7 @@ struct eec_encoder {
   eec_config cfg;
   Arena arena;
   bool packed = false;
-  bool has_stem = false, has_heads = false;  // eec_encoder_pack may be given layers only (building-block use)
+  bool has_stem = false, has_stem1 = false, has_heads = false;  // eec_encoder_pack may be given layers only (building-block use)
   // optional per-kernel-class timing with HIP events on the launch stream (bench/roofline only)
   bool profiling = false;
   std::vector<hipEvent_t> ev;       // pairs: start, stop
@@ -276,6 +276,12 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.final_ln_b, s.final_ln_b, D));
   }
   enc->has_stem = p->sub0_w && p->sub0_b && p->sub1_w && p->sub1_b && p->pe;
+  enc->has_stem1 = p->sub0_w && p->sub0_b && p->pe;  // enough for the one-convolution stem (eec_encoder_stem1_forward)
+  if (enc->has_stem1 && !enc->has_stem) {
+    EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
+    EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+    EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
+  }
   if (enc->has_stem) {
     EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
     EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
@@ -334,6 +340,12 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
     EEC_HIP(cp(L.final_ln_b, p->group_ln_b[e], D));
   }
   enc->has_stem = p->sub0_w && p->sub0_b && p->sub1_w && p->sub1_b && p->pe;
+  enc->has_stem1 = p->sub0_w && p->sub0_b && p->pe;  // enough for the one-convolution stem (eec_encoder_stem1_forward)
+  if (enc->has_stem1 && !enc->has_stem) {
+    EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
+    EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
+    EEC_HIP(cp(enc->pe, p->pe, (size_t)c.max_len * D));
+  }
   if (enc->has_stem) {
     EEC_HIP(launch_pack_frags(p->sub0_w, D, c.n_mels * 3, enc->sub_w1p, 1.0f, st));
     EEC_HIP(cp(enc->sub_b1, p->sub0_b, D));
@@ -669,6 +681,19 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
     }
     TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, np_o, true, !last, false, st));
   }
+  return 0;
+}
+
+int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, float* x, void* stream) {
+  if (!enc || !mel || !x) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (!enc->packed || !enc->has_stem1) return fail(EEC_ERR_NOT_PACKED, "no packed stem parameters");
+  if (B <= 0 || T < 3) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 3");
+  const eec_config& c = enc->cfg;
+  const int T1 = (T - 3) / 2 + 1;
+  if (T1 > c.max_len) return fail(EEC_ERR_BAD_ARG, "T1 exceeds the positional-encoding table (max_len)");
+  hipStream_t st = (hipStream_t)stream;
+  SubsampleArgs a{mel, B, c.n_mels, T, T1, T1, enc->sub_w1p, enc->sub_b1, nullptr, nullptr, enc->pe, nullptr, nullptr, x};
+  TIMED(KC_STEM, launch_subsample_single(a, st));
   return 0;
 }
 

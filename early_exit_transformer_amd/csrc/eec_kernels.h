@@ -126,6 +126,7 @@ struct SubsampleArgs {
   float* x;               // [B*Tq][256]
 };
 hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st);
+hipError_t launch_subsample_single(const SubsampleArgs& a, hipStream_t st);  // conv1 only: x = conv + bias + pe (mid / w2p / b2 unused)
 
 // weight packing (device -> device)
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // out may point into a larger matrix: n-tile nt0 of [N'][K] starts at out + nt0*(K/16)*128  // scale*W[N][K] -> fragments

@@ -18,7 +18,9 @@ constexpr int kSPF = 4;
 
 // ---------------------------------------------------------------------------
 // conv1.  K1 = n_mels * 3 (multiple of 16, <= 384); plane row stride (K1 + 8) halves.
-template <int NP>
+// DIRECT: the one-convolution stem of Early_zipformer (Conv1dSubampling_Zipformer, early_exit.py:80-95): the result
+// leaves as fp32 x[b][t1][:] = conv + bias + pe[t1] instead of the scaled fp16 planes that feed conv2.
+template <int NP, bool DIRECT>
 __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
@@ -69,6 +71,24 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleAr
   }
   const char* a_lane = smem + (lane & 31) * ld + hh * 16;
   gemm_plain_ring<NP, kSPF>(acc, a_lane, ld, plane, w_lane, ks, r);
+  if constexpr (DIRECT) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int row = row0 + mt * 32 + (lane & 31);
+      if (row < M1) {
+        const int t1 = row % a.T1;
+        float* dst = a.x + (size_t)row * kD + 32 * w + 4 * hh;
+        const float* pe = a.pe + (size_t)t1 * kD + 32 * w + 4 * hh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 p = *(const float4*)(pe + 8 * g);
+          *(float4*)(dst + 8 * g) = make_float4(acc[mt][0][4 * g + 0] * 64.f + p.x, acc[mt][0][4 * g + 1] * 64.f + p.y,
+                                                acc[mt][0][4 * g + 2] * 64.f + p.z, acc[mt][0][4 * g + 3] * 64.f + p.w);
+        }
+      }
+    }
+    return;
+  }
   // mid planes [B*T1][256] (scaled domain): lane = row, register quad = 4 consecutive channels
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -158,7 +178,7 @@ hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st) {
   if (K1 % 16 || K1 > 384) return hipErrorInvalidValue;
   const int lds1 = 2 * kTileRows * (K1 + 8) * 2;
   static bool d1[2] = {false, false}, d2[2] = {false, false};
-  auto k1 = np == 3 ? stem_conv1_kernel<3> : stem_conv1_kernel<1>;
+  auto k1 = np == 3 ? stem_conv1_kernel<3, false> : stem_conv1_kernel<1, false>;
   auto k2 = np == 3 ? stem_conv2_kernel<3> : stem_conv2_kernel<1>;
   const int v = np == 3;
   if (!d1[v]) {
@@ -176,6 +196,22 @@ hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k2, dim3((a.Tq + kTileRows - 1) / kTileRows, a.B), dim3(kStemThreads), kStem2Lds, st, a);
+  return hipGetLastError();
+}
+
+// one Conv1d(k=3, s=2) + PE: x [B][T1][256] fp32 (the Early_zipformer stem); hi/lo split operands
+hipError_t launch_subsample_single(const SubsampleArgs& a, hipStream_t st) {
+  const int K1 = a.n_mels * 3;
+  if (K1 % 16 || K1 > 384) return hipErrorInvalidValue;
+  static bool done = false;
+  auto k1 = stem_conv1_kernel<3, true>;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileRows * (384 + 8) * 2);
+    if (e != hipSuccess) return e;
+    done = true;
+  }
+  const int M1 = a.B * a.T1;
+  hipLaunchKernelGGL(k1, dim3((M1 + kTileRows - 1) / kTileRows), dim3(kStemThreads), 2 * kTileRows * (K1 + 8) * 2, st, a);
   return hipGetLastError();
 }
 

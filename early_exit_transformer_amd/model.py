@@ -72,6 +72,7 @@ class _HipEncoderMixin:
         self._enc = None
         self._packed_key = None
         self._ws: Dict[Tuple[int, int, int], Tensor] = {}
+        self._gws: Dict[Tuple[int, int, int], Tensor] = {}  # workspaces of the group-level entry points
         self._keep: list = []
 
     def __del__(self):
@@ -119,6 +120,24 @@ class _HipEncoderMixin:
                                 ptr(f"{self._pe_attr}.pe"), layers, hw, hb)
         stream = torch.cuda.current_stream(device).cuda_stream
         capi.check(lib.eec_encoder_pack(self._enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
+
+    def _group(self, enc_handle, group: int, x: Tensor, key_len: Tensor) -> None:
+        """x [B, T', D] fp32 contiguous, in place; key_len [B] int32 on the device."""
+        lib, dev = capi.load(), x.device
+        B, Tq, _ = x.shape
+        k = (B, Tq, dev.index or 0)
+        ws = self._gws.get(k)
+        if ws is None:
+            if len(self._gws) > 4:
+                self._gws.clear()
+            ws = torch.empty(lib.eec_encoder_group_workspace_bytes(enc_handle, B, Tq) + 256, dtype=torch.uint8, device=dev)
+            self._gws[k] = ws
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.eec_encoder_group_forward(enc_handle, group, x.data_ptr(), key_len.data_ptr(), B, Tq,
+                                           capi.PRECISIONS[self.precision], ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
+                                           C.c_void_p(stream))
+        capi.check(rc, "eec_encoder_group_forward")
 
     # -- measurement hook -----------------------------------------------------
     def set_profiling(self, enable: bool, max_launches: int = 8192) -> None:
@@ -268,7 +287,6 @@ class Splitformer(Early_conformer):
                                        dec_voc_size, max_len, capi.ARCH_CONFORMER)
         self._par_enc = None
         self._par_key = None
-        self._gws: Dict[Tuple[int, int, int], Tensor] = {}
 
     def __del__(self):
         enc = getattr(self, "_par_enc", None)
@@ -302,24 +320,6 @@ class Splitformer(Early_conformer):
         capi.check(lib.eec_encoder_pack(self._par_enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
         self._par_key = key
 
-    def _group(self, enc_handle, group: int, x: Tensor, key_len: Tensor) -> None:
-        """x [B, T', D] fp32 contiguous, in place; key_len [B] int32 on the device."""
-        lib, dev = capi.load(), x.device
-        B, Tq, _ = x.shape
-        k = (B, Tq, dev.index or 0)
-        ws = self._gws.get(k)
-        if ws is None:
-            if len(self._gws) > 4:
-                self._gws.clear()
-            ws = torch.empty(lib.eec_encoder_group_workspace_bytes(enc_handle, B, Tq) + 256, dtype=torch.uint8, device=dev)
-            self._gws[k] = ws
-        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        rc = lib.eec_encoder_group_forward(enc_handle, group, x.data_ptr(), key_len.data_ptr(), B, Tq,
-                                           capi.PRECISIONS[self.precision], ws_ptr, ws.numel() - (ws_ptr - ws.data_ptr()),
-                                           C.c_void_p(stream))
-        capi.check(rc, "eec_encoder_group_forward")
-
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
         # stem (+ PE) through the monolithic entry's first sub-step; also validates src and packs the main handle
         x = self._run_encoder(src, lengths, want_out=False, stop_after=0, want_x=True)[2]
@@ -348,6 +348,102 @@ class Splitformer(Early_conformer):
                 rc = lib.eec_encoder_head_forward(self._enc, index, x.data_ptr(), B * Tq, out[index].data_ptr(),
                                                   capi.PRECISIONS[self.precision], C.c_void_p(stream))
                 capi.check(rc, "eec_encoder_head_forward")
+        return out
+
+
+class Conv1dSubampling_Zipformer(nn.Module):
+    """Parameter holder for the one-convolution stem (early_exit.py:80-95)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=3, stride=2, padding=0)
+
+
+class Early_zipformer(_HipEncoderMixin, nn.Module):
+    """Drop-in for the reference's ``Early_zipformer`` (early_exit.py:117-224): one-convolution stem,
+    two Conformer groups at full frame rate, five stacks of groups at 1/2, 1/4, 1/8, 1/4, 1/2 rate with a skip around
+    each stack, one head on every second frame -> [1, B, ceil(T1/2), V].  Same kwargs, ``forward(src, lengths)`` and
+    state_dict names; ``n_enc_exits`` is the number of Conformer groups and must be >= 19 (the forward indexes groups
+    0 .. 18).  Stem, every group and the head run in libeec; pad / stride / repeat / add are torch ops."""
+
+    factors = (2, 4, 8, 4, 2)
+    stack = (2, 4, 5, 4, 2)
+
+    def __init__(self, src_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head, max_len,
+                 d_feed_forward, n_enc_layers, features_length, drop_prob, depthwise_kernel_size, device=None):
+        nn.Module.__init__(self)
+        if n_enc_exits < 2 + sum(self.stack):
+            raise ValueError(f"Early_zipformer indexes Conformer groups 0 .. {1 + sum(self.stack)}: n_enc_exits must be >= "
+                             f"{2 + sum(self.stack)}")
+        self.n_enc_exits, self.dropout, self.device, self.src_pad_idx = n_enc_exits, drop_prob, device, src_pad_idx
+        self.downsampling = nn.ModuleList([_TimeResample(f) for f in self.factors])
+        self.downsampling_output = _TimeResample(2)
+        self.upsampling = nn.ModuleList([_TimeResample(f) for f in self.factors])
+        self.conv_subsample = Conv1dSubampling_Zipformer(features_length, d_model)
+        self.positional_encoder = PositionalEncoding(d_model, drop_prob, max_len)
+        self.linear = nn.Linear(d_model, dec_voc_size)
+        self.conformer = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_feed_forward, num_layers=n_enc_layers,
+                      depthwise_conv_kernel_size=depthwise_kernel_size, dropout=drop_prob)
+            for _ in range(n_enc_exits)])
+        self._hip_init(d_model, n_head, d_feed_forward, depthwise_kernel_size, n_enc_exits, n_enc_layers,
+                       features_length, dec_voc_size, max_len)
+
+    def _param_tensors(self) -> List[Tensor]:
+        return list(self.conv_subsample.parameters()) + list(self.conformer.parameters()) + \
+            list(self.conformer.buffers()) + list(self.linear.parameters()) + [self.positional_encoder.pe]
+
+    def _pack(self, lib, device, sd, ptr) -> None:
+        E, L = self._cfg.n_exits, self._cfg.layers_per_exit
+        hw = (C.c_void_p * E)(*[ptr("linear.weight")] * E)  # one head, registered under every exit index
+        hb = (C.c_void_p * E)(*[ptr("linear.bias")] * E)
+        params = capi.EecParams(ptr("conv_subsample.conv.weight"), ptr("conv_subsample.conv.bias"), None, None,
+                                ptr("positional_encoder.pe"), _layer_params(ptr, "conformer", E, L), hw, hb)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        capi.check(lib.eec_encoder_pack(self._enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
+
+    def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        if not src.is_cuda:
+            raise RuntimeError("the MI355X encoder runs on a HIP device only (there is no CPU fallback -- the CPU "
+                               "reference lives in oracle/).")
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training is not built yet; call under model.eval() / torch.no_grad()")
+        if src.dim() != 3 or src.size(1) != self._cfg.n_mels or src.size(2) < 3:
+            raise ValueError(f"src must be [B, {self._cfg.n_mels}, T >= 3], got {tuple(src.shape)}")
+        dev = src.device
+        with torch.cuda.device(dev):
+            self._ensure_packed(dev)
+            lib = capi.load()
+            src = src.contiguous().float()
+            B, _, T = src.shape
+            T1, D, V = (T - 3) // 2 + 1, self._cfg.d_model, self._cfg.vocab
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            enc = torch.empty((B, T1, D), dtype=torch.float32, device=dev)
+            capi.check(lib.eec_encoder_stem1_forward(self._enc, src.data_ptr(), B, T, enc.data_ptr(), C.c_void_p(stream)),
+                       "eec_encoder_stem1_forward")
+            mel_len = lengths.to(device=dev, dtype=torch.int64)
+            base = torch.clamp(mel_len / 2, max=T1).to(torch.int32)
+            self._group(self._enc, 0, enc, base)
+            self._group(self._enc, 1, enc, base)
+            first = 2
+            for factor, count in zip(self.factors, self.stack):
+                skip = enc
+                n = enc.size(1)
+                pad = (-n) % factor
+                if pad:
+                    enc = torch.cat((enc, enc.new_zeros(B, pad, D)), dim=1)
+                enc = enc[:, ::factor, :].contiguous()  # a fresh tensor: the groups below run in place
+                key_len = torch.clamp((mel_len + pad) / factor, max=enc.size(1)).to(torch.int32)
+                for g in range(first, first + count):
+                    self._group(self._enc, g, enc, key_len)
+                first += count
+                enc = torch.repeat_interleave(enc, factor, dim=1)[:, :n, :] + skip
+            rows = enc[:, ::2, :].contiguous()
+            out = torch.empty((1, B, rows.size(1), V), dtype=torch.float32, device=dev)
+            rc = lib.eec_encoder_head_forward(self._enc, 0, rows.data_ptr(), B * rows.size(1), out.data_ptr(),
+                                              capi.PRECISIONS[self.precision], C.c_void_p(stream))
+            capi.check(rc, "eec_encoder_head_forward")
+            src.record_stream(torch.cuda.current_stream(dev))
         return out
 
 

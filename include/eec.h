@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 5
+#define EEC_ABI_VERSION 6
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -155,8 +155,12 @@ int eec_encoder_forward_prefix(eec_encoder* enc, const float* mel, const int64_t
  *   eec_encoder_group_forward: x [B, T', D] fp32, in place, through the layers_per_exit Conformer layers of `group`
  *       (= one torchaudio Conformer.forward(x, lengths), early_exit.py:603-615,627); key_len [B] int32 on the device:
  *       keys >= key_len[b] are masked (the caller applies the reference's length rule); production launch plan.
- *   eec_encoder_head_forward:  out [M, V] = log_softmax(x [M, D] . W_exit^T + b_exit)   (early_exit.py:629-631). */
+ *   eec_encoder_head_forward:  out [M, V] = log_softmax(x [M, D] . W_exit^T + b_exit)   (early_exit.py:629-631).
+ *   eec_encoder_stem1_forward: x [B, T1, D] = Conv1d(k=3, s=2)(mel) + bias + pe[t1], T1 = (T - 3) / 2 + 1: the
+ *       one-convolution stem of Early_zipformer (Conv1dSubampling_Zipformer, early_exit.py:80-95, 175-176); needs
+ *       sub0_w, sub0_b and pe at pack time (sub1_* may be NULL). */
 size_t eec_encoder_group_workspace_bytes(const eec_encoder* enc, int B, int Tq);
+int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, float* x, void* stream);
 int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32_t* key_len, int B, int Tq, int precision,
                               void* workspace, size_t workspace_bytes, void* stream);
 int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, float* out, int precision, void* stream);

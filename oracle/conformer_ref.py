@@ -258,6 +258,64 @@ class SplitformerRef(EarlyConformerRef):
         return torch.cat(outs)
 
 
+class _SingleConvStem(nn.Module):
+    """Conv1dSubampling_Zipformer (early_exit.py:80-95): one Conv1d(k=3, s=2)."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=3, stride=2, padding=0)
+
+    def forward(self, x: Tensor) -> Tensor:
+        return self.conv(x)
+
+
+class EarlyZipformerRef(nn.Module):
+    """Restatement of Early_zipformer (early_exit.py:117-224): one-convolution stem (T1 = (T-3)//2+1 frames), two
+    Conformer groups at full rate, then five stacks of groups at 1/2, 1/4, 1/8, 1/4, 1/2 of the frame rate -- each
+    stack: zero-pad to a multiple of the factor, keep every factor-th frame, run its groups, repeat every frame
+    factor times, drop the padding, add the stack's input -- and ONE head on every second frame.  The module list
+    has n_enc_exits groups of n_enc_layers layers and the forward indexes groups 0 .. 18, so n_enc_exits >= 19.
+    Reference quirk kept: inside the stacks the key lengths are ``clamp((mel_lengths + pad) / factor, max=T_stack)``."""
+
+    factors = (2, 4, 8, 4, 2)
+    stack = (2, 4, 5, 4, 2)
+
+    def __init__(self, src_pad_idx, n_enc_exits, enc_voc_size, dec_voc_size, d_model, n_head,
+                 max_len, d_feed_forward, n_enc_layers, features_length, drop_prob,
+                 depthwise_kernel_size, device="cpu"):
+        super().__init__()
+        self.conv_subsample = _SingleConvStem(features_length, d_model)
+        self.positional_encoder = SinusoidPE(d_model, drop_prob, max_len)
+        self.linear = nn.Linear(d_model, dec_voc_size)
+        self.conformer = nn.ModuleList([
+            Conformer(input_dim=d_model, num_heads=n_head, ffn_dim=d_feed_forward,
+                      num_layers=n_enc_layers, depthwise_conv_kernel_size=depthwise_kernel_size,
+                      dropout=drop_prob)
+            for _ in range(n_enc_exits)])
+
+    def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        enc = self.positional_encoder(self.conv_subsample(src).permute(0, 2, 1))
+        base = torch.clamp(lengths / 2, max=enc.size(1)).to(torch.int)
+        enc, _ = self.conformer[0](enc, base)
+        enc, _ = self.conformer[1](enc, base)
+        first = 2
+        for factor, count in zip(self.factors, self.stack):
+            skip = enc
+            pad = (-enc.size(1)) % factor
+            if pad:
+                enc = torch.cat((enc, enc.new_zeros(enc.size(0), pad, enc.size(2))), dim=1)
+            enc = enc[:, ::factor, :]
+            length = torch.clamp((lengths + pad) / factor, max=enc.size(1)).to(torch.int)
+            for group in self.conformer[first:first + count]:
+                enc, _ = group(enc, length)
+            first += count
+            enc = torch.repeat_interleave(enc, factor, dim=1)
+            if pad:
+                enc = enc[:, :-pad, :]
+            enc = enc + skip
+        return F.log_softmax(self.linear(enc[:, ::2, :]), dim=2).unsqueeze(0)
+
+
 def trace_substeps(model: "EarlyConformerRef", src: Tensor, lengths: Tensor) -> List[Tensor]:
     """Residual stream [B, T', D] after the stem and after every sub-step of every layer
     (ffn1, attention, conv, ffn2+final LN) -- the checkpoints ``eec_encoder_forward(stop_after=k)``

@@ -57,6 +57,33 @@ def test_splitformer_oracle_equals_reference_class_body():
             assert torch.equal(ref(mel, lt), mine(mel, lt))
 
 
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree only exists in the build container")
+def test_zipformer_oracle_equals_reference_class_body():
+    """the reference's Early_zipformer (early_exit.py:117-224), imported unmodified, equals
+    oracle.EarlyZipformerRef bit for bit (632 state_dict keys at 19 one-layer groups)."""
+    ee = _import_reference()
+    kw = base_kwargs(n_enc_exits=19, n_enc_layers=1, d_feed_forward=128, depthwise_kernel_size=7, dec_voc_size=64)
+    ref, mine = ee.Early_zipformer(**kw).eval(), R.EarlyZipformerRef(**kw).eval()
+    assert sorted(ref.state_dict().keys()) == sorted(mine.state_dict().keys())
+    sd = synth.synth_state_dict(ref.state_dict(), seed=6, style="trained")
+    ref.load_state_dict(sd, strict=True)
+    mine.load_state_dict(sd, strict=True)
+    for T, lens in ((203, [203, 150]), (211, [120, 211]), (330, [330, 64])):
+        mel, lt = synth.synth_mel(2, 80, T, seed=6), torch.tensor(lens)
+        with torch.no_grad():
+            assert torch.equal(ref(mel, lt), mine(mel, lt))
+
+
+def test_zipformer_oracle_reproduces_golden():
+    z, kw = load_golden("zipformer_small")
+    model = R.EarlyZipformerRef(**kw).eval()
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), seed=int(z["seed"]), style="trained"), strict=True)
+    for i, (B, T, lens) in enumerate(eval(str(z["cases"]))):
+        with torch.no_grad():
+            out = model(synth.synth_mel(B, 80, T, seed=int(z["seed"]) + i), torch.tensor(lens))
+        assert torch.allclose(out, torch.from_numpy(z[f"logp{i}"]), atol=2e-5)
+
+
 def test_splitformer_oracle_reproduces_golden():
     z, kw = load_golden("splitformer_small")
     model = R.SplitformerRef(**kw).eval()
