@@ -64,13 +64,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback; the CPU oracle is only the baseline leg)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (a one-GPU box cannot host two RCCL ranks): EEC_BENCH_BACKEND=gloo EEC_BENCH_DEVICE=0 runs the N > 1
+    # control flow -- barriers, the loss all-reduce, the max-over-ranks timing -- with every rank on the same device
+    backend = os.environ.get("EEC_BENCH_BACKEND", "nccl")
+    dev_index = int(os.environ.get("EEC_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from early_exit_transformer_amd import parallel, synth
     from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses
