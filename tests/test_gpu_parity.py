@@ -221,6 +221,19 @@ def test_early_exit_prefix_equals_full_forward(prec):
         gpu._run_encoder(mel.cuda(), lens, n_groups=5)
 
 
+def test_more_exits_than_the_batched_head_launch_holds():
+    """17 exits: above the 16 per-exit pointer slots of the batched head launch, so the heads fall back to one
+    launch per exit (same kernel body)."""
+    kw = base_kwargs(n_enc_exits=17, n_enc_layers=1, d_feed_forward=128, depthwise_kernel_size=7, dec_voc_size=32)
+    ref, gpu = make_pair(kw, seed=71)
+    mel, lens = synth.synth_mel(2, 80, 139, seed=71), torch.tensor([139, 60])
+    with torch.no_grad():
+        want = ref(mel, lens)
+    got = run_gpu(gpu, mel, lens, "f16x3")
+    assert got.shape == want.shape and got.shape[0] == 17
+    assert (got - want).abs().max().item() < TOL["f16x3"]
+
+
 def test_full_conformer_encoder_taps_golden():
     """config 5 substitute: full_conformer._encoder_(src, lengths, n) (early_exit.py:719-737), fixture from the
     reference's own full_conformer."""
