@@ -370,7 +370,11 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
   for (int nt = 0; nt < NT; ++nt) {
     const uint4* r = rec_lane + nt * nt_stride - lane_id();
     g.lo[nt][0] = r[256 + 2 * lane_id()];
+#ifdef EEC_LO_HALF  // timing-only build: half the residual bytes (what an fp4 residual would stream)
+    g.lo[nt][1] = g.lo[nt][0];
+#else
     g.lo[nt][1] = r[256 + 2 * lane_id() + 1];
+#endif
     g.sc[nt] = ((const int*)(r + 384))[lane_id()];
   }
 }
@@ -382,7 +386,7 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 // NW: number of lo8 group buffers.  NW == NG: the whole stage is resident (loaded by the caller one stage ahead);
 // NW < NG: rolling buffers, group g lives in wg[g % NW] and is refilled with group g + NW right after its use
 // (the caller preloads groups 0 .. NW-1 of the next stage).
-template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG>
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0>
 __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
                                              int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
                                              WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side()) {
@@ -449,12 +453,13 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
         for (int mt = 0; mt < 2; ++mt) {
           const i32x8 ahi = {(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
                              (int)a8[mt][2].x, (int)a8[mt][2].y, (int)a8[mt][3].x, (int)a8[mt][3].y};
+          // DROP (diagnostic builds only): bit 0 skips the activation-residual term, bit 1 the weight-residual term
           if (SWAP) {
-            acc[mt][nt] = mfma_f8(whi, alo[mt], acc[mt][nt], kE8M0One, kE8M0One);
-            acc[mt][nt] = mfma_f8(wlo, ahi, acc[mt][nt], G.sc[nt], kE8M0One);
+            if (!(DROP & 1)) acc[mt][nt] = mfma_f8(whi, alo[mt], acc[mt][nt], kE8M0One, kE8M0One);
+            if (!(DROP & 2)) acc[mt][nt] = mfma_f8(wlo, ahi, acc[mt][nt], G.sc[nt], kE8M0One);
           } else {
-            acc[mt][nt] = mfma_f8(alo[mt], whi, acc[mt][nt], kE8M0One, kE8M0One);
-            acc[mt][nt] = mfma_f8(ahi, wlo, acc[mt][nt], kE8M0One, G.sc[nt]);
+            if (!(DROP & 1)) acc[mt][nt] = mfma_f8(alo[mt], whi, acc[mt][nt], kE8M0One, kE8M0One);
+            if (!(DROP & 2)) acc[mt][nt] = mfma_f8(ahi, wlo, acc[mt][nt], kE8M0One, G.sc[nt]);
           }
         }
       }

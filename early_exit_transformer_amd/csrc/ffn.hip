@@ -52,13 +52,21 @@ template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF
 #define EEC_PF2_NP8 3
 #endif
 template <> struct FfnPf<8> { static constexpr int P1 = EEC_PF1_NP8, P2 = EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+#ifndef EEC_DROP1
+#define EEC_DROP1 0  // diagnostic: correction terms of GEMM1 / GEMM2 to skip (see gemm_ring_f8)
+#define EEC_DROP2 0
+#endif
 #ifndef EEC_SIDE_VALU_NP8
 #define EEC_SIDE_VALU_NP8 5  // VALU instructions of the SiLU side work pinned behind each MFMA of GEMM1 (f8 stream)
 #endif
 #ifndef EEC_NW1
 #define EEC_NW1 4
 #endif
-constexpr int kNW1 = EEC_NW1;  // lo8 group buffers of the producers' GEMM1 (4 = whole stage resident)
+constexpr int kNW1 = EEC_NW1;
+#ifndef EEC_NW2
+#define EEC_NW2 1
+#endif
+constexpr int kNW2 = EEC_NW2;  // lo8 group buffers of the consumers' GEMM2 (2 = whole stage resident)  // lo8 group buffers of the producers' GEMM1 (4 = whole stage resident)
 constexpr int kH8Ld = kFC + 16;  // 144: H lo8 byte plane row stride (NP == 8)
 
 #ifdef EEC_TIMELINE
@@ -222,7 +230,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   WRing<RNP, kPF1, 1> r1;
   WRing<RNP, kPF2, 2> r2;
   WGroupF8<1> wg1[kNW1];  // NP == 8: lo8 + scales of GEMM1 (K = 256 = 4 groups), rolling through kNW1 buffers
-  WGroupF8<2> wg2[2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, 2 n-tiles)
+  WGroupF8<2> wg2[kNW2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, 2 n-tiles)
   const size_t w2f8_nt = (size_t)(F / 64) * kF8Rec;
   auto w1f8_lane = [&](const WPtrs& W, int ft) { return W.w1f8 + (size_t)ft * 4 * kF8Rec + lane; };
   auto w2f8_lane = [&](const WPtrs& W, int c) { return W.w2f8 + ((size_t)(2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     if constexpr (NP == 8) {
       ring_fill_f8<kPF2, 2>(r2, w2f8_lane(W, c), w2f8_nt);
 #pragma unroll
-      for (int g = 0; g < 2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
+      for (int g = 0; g < kNW2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
     } else {
       ring_fill<RNP, kPF2, 2>(r2, W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
                              min(kFC / 16, ks2_total - c * (kFC / 16)));
@@ -365,13 +373,13 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           if (do_silu) {
             auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
             if constexpr (NP == 8)
-              gemm_ring_f8<4, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
+              gemm_ring_f8<4, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
               gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
                                                                                        0, r1, side);
           } else {
             if constexpr (NP == 8)
-              gemm_ring_f8<4, 1, true, kPF1, NoSide, 0, kNW1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
+              gemm_ring_f8<4, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
             else
               gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
           }
@@ -422,7 +430,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           const uint4* w2_lane = W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
           if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
             const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
-            gemm_ring_f8<2, 2, false, kPF2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
+            gemm_ring_f8<2, 2, false, kPF2, NoSide, 0, kNW2, EEC_DROP2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
           } else if (ks2 == kFC / 16) {
             gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
           } else {
