@@ -190,7 +190,9 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   EEC_TL_STAMP(attn, 3);
   if (!active) return;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  // an utterance with NO valid key (lengths < 4 mel frames -> length 0): every key is masked and the installed
+  // torch (>= 2.5, the oracle's) returns zeros for such rows ("safe softmax"); nothing was accumulated, so O = 0
+  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   const int q = q0 + r;
   if (q < a.Tq) {
     const size_t rowoff = ((size_t)b * a.Tq + q) * kD + hd * DH;

@@ -150,6 +150,7 @@ def test_fused_plan_equals_substep_plan(prec):
     (5, 403, [403, 402, 300, 77, 5]),  # T' = 99: not a multiple of 32; M = 495 not a multiple of 64; len -> 1
     (2, 1100, [1100, 640]),          # T' = 274 > 256: two key chunks in the attention kernel
     (3, 259, [259, 259, 259]),       # no padding at all
+    (4, 61, [1, 8, 61, 3]),          # lengths < 4 -> encoder length 0: every key masked (torch's safe softmax: zeros)
 ])
 def test_ragged_shapes(B, T, lens):
     kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256)
