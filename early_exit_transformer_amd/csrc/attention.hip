@@ -27,6 +27,7 @@ struct AttnLds {
   static constexpr int KBYTES = kKC * KLD;
   static constexpr int VBYTES = DH * VLD;
   static constexpr int TOTAL = KBYTES + VBYTES;
+  static constexpr int TOTAL2 = KBYTES + 2 * VBYTES;  // with the residual plane of V^T
 };
 
 EEC_TL_DEFINE(attn)
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_k = smem;
   char* lds_v = smem + L::KBYTES;
+  char* lds_vlo = lds_v + L::VBYTES;  // only allocated / used when a.vt_lo is given
+  const bool v2 = a.vt_lo != nullptr;  // uniform
   const int lane = lane_id(), w = wave_id();
   const int r = lane & 31, hh = lane >> 5;
   const int b = blockIdx.z, hd = blockIdx.y;
@@ -86,6 +89,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
 
   const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
   const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
+  const half_t* vlbase = v2 ? a.vt_lo + (size_t)bh * DH * a.Tp : vbase;
   for (int kc0 = 0; kc0 < len; kc0 += kKC) {
     if (kc0) __syncthreads();
     // stage K rows [kc0, kc0+KC) and V^T columns of the same keys; zero beyond Tp.  All global loads of
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       constexpr int VP = kKC / 8;
       constexpr int KIT = kKC * KP / kAttnThreads, VIT = DH * VP / kAttnThreads;
       static_assert(kKC * KP % kAttnThreads == 0 && DH * VP % kAttnThreads == 0, "staging loops assume whole passes");
-      uint4 kv[KIT], vv[VIT];
+      uint4 kv[KIT], vv[VIT], vl[VIT];
 #pragma unroll
       for (int it = 0; it < KIT; ++it) {
         const int p = it * kAttnThreads + threadIdx.x, row = p / KP, c = p % KP;
@@ -106,7 +110,11 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       for (int it = 0; it < VIT; ++it) {
         const int p = it * kAttnThreads + threadIdx.x, row = p / VP, c = p % VP;
         vv[it] = make_uint4(0, 0, 0, 0);
-        if (kc0 + c * 8 < a.Tp) vv[it] = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
+        vl[it] = make_uint4(0, 0, 0, 0);
+        if (kc0 + c * 8 < a.Tp) {
+          vv[it] = *(const uint4*)(vbase + (size_t)row * a.Tp + kc0 + c * 8);
+          if (v2) vl[it] = *(const uint4*)(vlbase + (size_t)row * a.Tp + kc0 + c * 8);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -118,6 +126,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       for (int it = 0; it < VIT; ++it) {
         const int p = it * kAttnThreads + threadIdx.x, row = p / VP, c = p % VP;
         *(uint4*)(lds_v + row * L::VLD + c * 16) = vv[it];
+        if (v2) *(uint4*)(lds_vlo + row * L::VLD + c * 16) = vl[it];
       }
     }
     EEC_TL_STAMP(attn, 1);
@@ -180,8 +189,9 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
           if (kt0 + j < nkt) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-              const h8 vf = *(const h8*)(lds_v + (dt * 32 + r) * L::VLD + ((kt0 + j) * 32 + ks * 16 + 8 * hh) * 2);
-              o[dt] = mfma16(vf, pf[j][ks], o[dt]);
+              const int voff = (dt * 32 + r) * L::VLD + ((kt0 + j) * 32 + ks * 16 + 8 * hh) * 2;
+              o[dt] = mfma16(*(const h8*)(lds_v + voff), pf[j][ks], o[dt]);
+              if (v2) o[dt] = mfma16(*(const h8*)(lds_vlo + voff), pf[j][ks], o[dt]);
             }
           }
       }
@@ -215,8 +225,9 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
 template <int DH, int NP>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
   auto k = attn_kernel<DH, NP>;
-  constexpr int lds = AttnLds<DH>::TOTAL;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  constexpr int lds_max = AttnLds<DH>::TOTAL2;
+  const int lds = a.vt_lo ? AttnLds<DH>::TOTAL2 : AttnLds<DH>::TOTAL;
+  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.Tq + 32 * kAttnWaves - 1) / (32 * kAttnWaves), a.H, a.B), dim3(kAttnThreads), lds, st, a);
   return hipGetLastError();

@@ -158,7 +158,7 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   w.mid_lo = a.take<half_t>((size_t)B * T1 * D);
   w.q = a.take<half_t>((size_t)B * Tp * D);
   w.k = a.take<half_t>((size_t)B * Tp * D);
-  w.vt = a.take<half_t>((size_t)B * Tp * D);
+  w.vt = a.take<half_t>((size_t)2 * B * Tp * D);  // hi plane, then the residual plane
   w.p_hi = a.take<half_t>(M * D);
   w.p_lo = a.take<half_t>(M * D);
   w.g = a.take<half_t>(M * D);
@@ -392,6 +392,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
   // operand format per GEMM group of the production plan (all np_o; a diagnostic build can override them one by one)
   int np_qkv = np_o, np_att = np_o, np_glu = np_o, np_front = np_o, np_head = np_o;
+  half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * c.d_model : nullptr;  // V keeps its fp16 residual in the split modes
 #ifdef EEC_NP_EXPERIMENT
   if (const char* ov = getenv("EEC_NP_OVERRIDE")) {  // e.g. "qkv=1,glu=1": error-budget experiments (tools/np_budget.py)
     auto pick = [&](const char* key, int& dst) {
@@ -422,7 +423,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   } while (0)
 
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
-  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
+  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   {
     SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
     TIMED(KC_STEM, launch_subsample(a, 3, st));  // raw power mel: always hi/lo split (1 % of the flops)
@@ -437,9 +438,9 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       for (int l = 0; l < c.layers_per_exit; ++l) {
         const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
         {
-          QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+          QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
           TIMED(KC_QKV, launch_qkv(a, np_o, st));
-          AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+          AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
           TIMED(KC_ATTN, launch_attention(at, np_o, st));
           ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
           TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
@@ -475,7 +476,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
     // halo).  The sub-step hook (stop_after >= 0) uses the unfused plan below; both are parity-tested.
     const int n_layers = n_groups * c.layers_per_exit;
     auto qkv_args = [&](const PackedLayer& L) {
-      return QkvArgs{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+      return QkvArgs{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
     };
     auto stage1 = [&](const PackedLayer& L) {
       return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
@@ -499,7 +500,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       const PackedLayer& L = enc->layers[li];
       const int e = li / c.layers_per_exit;
       const bool exit_layer = (li + 1) % c.layers_per_exit == 0, last = li + 1 == n_layers;
-      AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+      AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
       TIMED(KC_ATTN, launch_attention(at, np_att, st));
       ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
       GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
@@ -541,9 +542,9 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       ++step;
       if (done()) return finish_dbg();
       {
-        QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+        QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
         TIMED(KC_QKV, launch_qkv(a, np_o, st));
-        AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+        AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
         ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
         GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
@@ -616,7 +617,7 @@ static GroupWs carve_group_ws(const eec_config& c, int B, int Tq, char* base) {
   GroupWs w;
   w.q = a.take<half_t>((size_t)B * Tp * D);
   w.k = a.take<half_t>((size_t)B * Tp * D);
-  w.vt = a.take<half_t>((size_t)B * Tp * D);
+  w.vt = a.take<half_t>((size_t)2 * B * Tp * D);  // hi plane, then the residual plane
   w.p_hi = a.take<half_t>(M * D);
   w.p_lo = a.take<half_t>(M * D);
   w.g = a.take<half_t>(M * D);
@@ -645,9 +646,10 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
   const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
-  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)B * Tp * D * sizeof(half_t), st));
+  half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * D : nullptr;
+  if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   auto qkv_args = [&](const PackedLayer& L) {
-    return QkvArgs{x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt};
+    return QkvArgs{x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
   };
   auto stage1 = [&](const PackedLayer& L) {
     return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
@@ -664,7 +666,7 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   for (int li = l0; li < l1; ++li) {
     const PackedLayer& L = enc->layers[li];
     const bool last = li + 1 == l1;
-    AttnArgs at{ws.q, ws.k, ws.vt, key_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo};
+    AttnArgs at{ws.q, ws.k, ws.vt, key_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
     TIMED(KC_ATTN, launch_attention(at, np_o, st));
     ProjResArgs pr{x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
     GluArgs ga{x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};

@@ -101,11 +101,19 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
     if (ok[mt]) {
-      half_t* dst = a.vt + ((size_t)(rb[mt] * a.H + hd) * dh + d0) * a.Tp + vt_perm(rt[mt]);
+      const size_t voff = ((size_t)(rb[mt] * a.H + hd) * dh + d0) * a.Tp + vt_perm(rt[mt]);
+      half_t* dst = a.vt + voff;
+      // V's own fp16 rounding is the largest single contribution of the attention path to the log-prob error
+      // (CPU emulation: 1.7e-4 of 2.5e-4 on the default model, 1.3e-3 on a stress configuration): keep the residual
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dst[(size_t)(8 * g + j) * a.Tp] = to_half_sat(acc[mt][0][4 * g + j]);
+        for (int j = 0; j < 4; ++j) {
+          const float v = acc[mt][0][4 * g + j];
+          const half_t hi = to_half_sat(v);
+          dst[(size_t)(8 * g + j) * a.Tp] = hi;
+          if (a.vt_lo) a.vt_lo[voff + (size_t)(8 * g + j) * a.Tp] = (half_t)(v - (float)hi);
+        }
     }
 }
 

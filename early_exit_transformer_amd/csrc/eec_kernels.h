@@ -30,6 +30,7 @@ struct QkvArgs {
   const uint4* wp;  // packed in_proj_weight [768][256]
   const float* bias;  // [768]
   half_t *q, *k, *vt;  // q,k: [B][H][Tp][dh]; vt: [B][H][dh][Tp] (key order permuted per 16)
+  half_t* vt_lo = nullptr;  // optional: fp16 residual V - fp16(V), same layout (the PV product then runs on hi + lo)
 };
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
@@ -79,6 +80,7 @@ struct AttnArgs {
   const int* enc_len;  // [B] valid encoder frames (keys >= len are masked)
   int B, H, Tq, Tp, dh;
   half_t *o_hi, *o_lo;  // [M][256]
+  const half_t* vt_lo = nullptr;  // optional residual plane of V^T (see QkvArgs)
 };
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st);
 
