@@ -197,6 +197,21 @@ def main():
                            "frac_of_mfma_peak": round(flop_fwd * args.steps / d / MFMA_PEAK_FLOPS, 4)}
         model.precision = args.precision
 
+    # ---- per-step distribution (median, p10 / p90): HIP events between consecutive steps of a second pass ----
+    step_ms = None
+    if rank == 0 and world == 1:
+        n_ev = min(args.steps, 50)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
+        run_steps(2)
+        evs[0].record()
+        for i in range(n_ev):
+            run_steps(1)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ts = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(n_ev))
+        step_ms = {"median": round(ts[n_ev // 2], 4), "p10": round(ts[n_ev // 10], 4), "p90": round(ts[(9 * n_ev) // 10], 4),
+                   "n": n_ev, "how": "hipEvent pairs around single steps on the launch stream"}
+
     # ---- secondary shapes: forward-only, same model; reported, never the headline ----
     secondary = {}
     if rank == 0 and world == 1 and not args.no_modes:
@@ -263,7 +278,7 @@ def main():
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
-            "modes": modes, "secondary_shapes": secondary,
+            "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
