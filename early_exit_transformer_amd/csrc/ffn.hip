@@ -10,11 +10,11 @@
 // One 512-thread workgroup owns 64 rows of x; the [64, F] hidden activation never leaves the CU.
 // F is walked in chunks of 128 hidden units.  The 8 waves are specialised (one wave of each kind
 // per SIMD):
-//   producers (waves 4-7): GEMM1 in the swapped orientation (lane = frame, register quad = 4
+//   producers (waves 0-3): GEMM1 in the swapped orientation (lane = frame, register quad = 4
 //       consecutive hidden units; wave wl makes hidden [32wl, 32wl+32) of the chunk for all 64
 //       rows; accumulators start at the bias), SiLU in the exp2 domain (log2 e folded into W1/b1,
 //       1/log2 e into W2), hi/lo split, ds_write_b64 into H[c & 1][frame][hidden];
-//   consumers (waves 0-3): GEMM2 (normal orientation) of chunk c-1 from H[(c-1) & 1], wave wl
+//   consumers (waves 4-7): GEMM2 (normal orientation) of chunk c-1 from H[(c-1) & 1], wave wl
 //       accumulating output columns [64wl, 64wl+64) in registers that live across all chunks.
 // In slot s the producers multiply chunk s and, inside that k-loop (two values per k-step, in the
 // shadow of the step's MFMAs), SiLU chunk s-1 into H[(s-1) & 1]; the consumers eat chunk s-2.  Both
@@ -70,7 +70,7 @@ constexpr int kNW2 = EEC_NW2;  // lo8 group buffers of the consumers' GEMM2 (2 =
 constexpr int kH8Ld = kFC + 16;  // 144: H lo8 byte plane row stride (NP == 8)
 
 #ifdef EEC_TIMELINE
-// Diagnostic build only: s_memtime stamps of wave 0 (producer) and wave 4 (consumer) of the first
+// Diagnostic build only: s_memtime stamps of wave 0 (consumer slot of the buffer) and wave 4 of the first
 // 8 workgroups, written to a buffer nothing else reads.  Layout: [block][role][stamp], 128 stamps.
 __device__ unsigned long long* g_timeline = nullptr;
 __device__ __forceinline__ void tl_stamp(int& idx) {
@@ -182,7 +182,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   const int lane = lane_id(), w = wave_id();
   const int hh = lane >> 5, wl = w & 3;
   const int w_s = wave_id_sgpr();
-  const bool is_producer = w >= 4;  // wave-uniform; consumers are the OLDER waves (issue arbitration: priority, then age)
+  // wave-uniform.  The producers are the OLDER waves (0-3): issue arbitration between the two waves of a SIMD goes by
+  // priority, then age, and the producers are the critical path of the chunk pipeline (measured -2.3 % forward against
+  // the opposite assignment; raising their priority with s_setprio instead makes it slower)
+  const bool is_producer = w < 4;
   const int row0 = blockIdx.x * kTileRows;
   const int M = a.M, F = a.F;
   float* __restrict__ x = a.x;

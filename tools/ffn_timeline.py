@@ -20,7 +20,7 @@ buf = (C.c_ulonglong * (8 * 2 * 128))()
 lib.eec_debug_timeline(buf, 8 * 2 * 128)
 a = np.array(buf, dtype=np.int64).reshape(8, 2, 128)
 for blk in (0, 3):
-    for role, nm in ((0, "consumer w0"), (1, "producer w4")):
+    for role, nm in ((0, "producer w0"), (1, "consumer w4")):
         t = a[blk, role]; n = int((t > 0).sum()); t = t[:n] - a[blk, 0, 0]
         print(f"block {blk} {nm}: {n} stamps; total {t[-1]} cycles (100MHz ticks? see deltas)")
         print("   ", " ".join(str(int(v)) for v in np.diff(t)))
