@@ -186,6 +186,75 @@ int check_cfg(const eec_config& c) {
 
 }  // namespace
 
+// TIMED(class, launch-expression): brackets the launch with events when profiling is on (uses `enc` and `st` of the caller)
+#define TIMED(cls, expr)                                                        \
+  do {                                                                          \
+    const bool _p = enc->profiling && (enc->ev_used + 1) * 2 <= enc->ev.size(); \
+    if (_p) EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2], st));             \
+    EEC_HIP(expr);                                                              \
+    if (_p) {                                                                   \
+      EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2 + 1], st));               \
+      enc->ev_class[enc->ev_used++] = (cls);                                    \
+    }                                                                           \
+  } while (0)
+
+// The production launch plan of Conformer layers [l0, l1) on rows x (in place): 3 launches per layer.  Everything that
+// is local to a 64-row tile runs in ONE chain kernel per layer boundary,
+//   [depthwise + pointwise-2 of layer l] -> ffn2(l) + final LN (+ tap) -> ffn1(l+1) -> in_proj(l+1),
+// and only the two steps with cross-tile dependencies keep their own launch: attention (all keys of the utterance) and
+// out_proj + LN + pointwise-1 + GLU (whose output the depthwise conv reads with a +-15 frame halo).  tap_of(li) says
+// where layer li's output is stored besides x (nullptr: nowhere; x itself moves on to ffn1 of layer li + 1).
+struct LayerBufs {
+  float* x;
+  half_t *q, *k, *vt, *vt_lo, *p_hi, *p_lo, *g;
+  const int* key_len;
+};
+struct LayerFormats {
+  int ffn, front, qkv, att, glu;  // operand formats of the GEMM groups (1, 3 or 8)
+};
+template <typename TapFn>
+static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, int B, int Tq, const LayerFormats& np,
+                          TapFn tap_of, hipStream_t st) {
+  const eec_config& c = enc->cfg;
+  const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
+  auto qkv_args = [&](const PackedLayer& L) {
+    return QkvArgs{b.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo};
+  };
+  auto stage1 = [&](const PackedLayer& L) {
+    return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
+                    L.ffn1_w1f8, L.ffn1_w2f8, 0.5f, nullptr};
+  };
+  {
+    ChainArgs ca{};
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
+    ca.st[0] = stage1(enc->layers[l0]);
+    ca.qkv = qkv_args(enc->layers[l0]);
+    TIMED(KC_CHAIN, launch_ffn_chain(ca, np.ffn, np.front, np.qkv, false, true, false, st));
+  }
+  for (int li = l0; li < l1; ++li) {
+    const PackedLayer& L = enc->layers[li];
+    const bool last = li + 1 == l1;
+    AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
+    TIMED(KC_ATTN, launch_attention(at, np.att, st));
+    ProjResArgs pr{b.x, M, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b};
+    GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g};
+    TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
+    ChainArgs ca{};
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
+    ca.dw = DwArgs{b.g, B, Tq, L.dw_wfold, L.dw_bfold, b.p_hi, b.p_lo};
+    ca.pw2 = ProjResArgs{b.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+    ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
+                        L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap_of(li)};
+    if (!last) {
+      ca.st[1] = stage1(enc->layers[li + 1]);
+      ca.qkv = qkv_args(enc->layers[li + 1]);
+    }
+    TIMED(KC_CHAIN, launch_ffn_chain(ca, np.ffn, np.front, np.qkv, true, !last, false, st));
+  }
+  return 0;
+}
+
+
 extern "C" {
 
 const char* eec_last_error(void) { return g_err.c_str(); }
@@ -410,17 +479,6 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
     return 0;
   };
 
-  // TIMED(class, launch-expression): brackets the launch with events when profiling is on
-#define TIMED(cls, expr)                                                        \
-  do {                                                                          \
-    const bool _p = enc->profiling && (enc->ev_used + 1) * 2 <= enc->ev.size(); \
-    if (_p) EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2], st));             \
-    EEC_HIP(expr);                                                              \
-    if (_p) {                                                                   \
-      EEC_HIP(hipEventRecord(enc->ev[enc->ev_used * 2 + 1], st));               \
-      enc->ev_class[enc->ev_used++] = (cls);                                    \
-    }                                                                           \
-  } while (0)
 
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
@@ -468,66 +526,34 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   }
 
   if (stop_after < 0) {
-    // Production plan: 3 launches per layer.  Everything that is local to a 64-row tile runs in ONE chain
-    // kernel per layer boundary:
-    //   [depthwise + pointwise-2 of layer l] -> ffn2(l) + final LN (+ exit tap) -> ffn1(l+1) -> in_proj(l+1)
-    // and only the two steps with cross-tile dependencies keep their own launch: attention (all keys of the
-    // utterance) and out_proj + LN + pointwise-1 + GLU (whose output the depthwise conv reads with a +-15 frame
-    // halo).  The sub-step hook (stop_after >= 0) uses the unfused plan below; both are parity-tested.
+    // production plan (run_layer_plan); the sub-step hook (stop_after >= 0) uses the unfused plan below; both are parity-tested
     const int n_layers = n_groups * c.layers_per_exit;
-    auto qkv_args = [&](const PackedLayer& L) {
-      return QkvArgs{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
-    };
-    auto stage1 = [&](const PackedLayer& L) {
-      return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
-                      L.ffn1_w1f8, L.ffn1_w2f8, 0.5f, nullptr};
-    };
-    auto stage2 = [&](const PackedLayer& L, float* tap) {
-      return FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
-                      L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap};
-    };
     const bool batch_heads = out && n_groups <= kMaxHeadExits;  // all exit heads in ONE launch after the last layer
-    HeadBatchArgs hb{};
-    hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = n_groups;
-    {
-      ChainArgs ca{};
-      ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
-      ca.st[0] = stage1(enc->layers[0]);
-      ca.qkv = qkv_args(enc->layers[0]);
-      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_front, np_qkv, false, true, false, st));
-    }
-    for (int li = 0; li < n_layers; ++li) {
-      const PackedLayer& L = enc->layers[li];
+    // where exit e's encoder output goes besides x: the caller's tap buffer, else (if a head needs it later) workspace rows
+    auto tap_of = [&](int li) -> float* {
+      if ((li + 1) % c.layers_per_exit != 0) return nullptr;
       const int e = li / c.layers_per_exit;
-      const bool exit_layer = (li + 1) % c.layers_per_exit == 0, last = li + 1 == n_layers;
-      AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
-      TIMED(KC_ATTN, launch_attention(at, np_att, st));
-      ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
-      GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
-      TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_glu, st));
-      float* tap = nullptr;  // where the exit's encoder output goes besides x (x itself moves on to ffn1 of the next layer)
-      if (exit_layer) tap = taps_opt ? taps_opt + (size_t)e * M * D : ((out && !last) ? ws.y + (size_t)e * M * D : nullptr);
-      ChainArgs ca{};
-      ca.x = ws.x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
-      ca.dw = DwArgs{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-      ca.pw2 = ProjResArgs{ws.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
-      ca.st[0] = stage2(L, tap);
-      if (!last) {
-        ca.st[1] = stage1(enc->layers[li + 1]);
-        ca.qkv = qkv_args(enc->layers[li + 1]);
-      }
-      TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_front, np_qkv, true, !last, false, st));
-      if (exit_layer && out) {
-        const float* rows = last ? ws.x : tap;
+      if (taps_opt) return taps_opt + (size_t)e * M * D;
+      return (out && li + 1 != n_layers) ? ws.y + (size_t)e * M * D : nullptr;
+    };
+    const LayerBufs bufs{ws.x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, ws.enc_len};
+    const LayerFormats nps{np_ffn, np_front, np_qkv, np_att, np_glu};
+    if (int rc = run_layer_plan(enc, 0, n_layers, bufs, B, Tq, nps, tap_of, st)) return rc;
+    if (out) {
+      HeadBatchArgs hb{};
+      hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = n_groups;
+      for (int e = 0; e < n_groups; ++e) {
+        const int li = (e + 1) * c.layers_per_exit - 1;
+        const float* rows = li + 1 == n_layers ? ws.x : tap_of(li);
         if (batch_heads) {
           hb.x[e] = rows, hb.wp[e] = enc->head_p[e], hb.bias[e] = enc->head_b[e];
         } else {
           HeadArgs h{rows, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
-          TIMED(KC_HEAD, launch_head(h, np_o, st));
+          TIMED(KC_HEAD, launch_head(h, np_head, st));
         }
       }
+      if (batch_heads) TIMED(KC_HEAD, launch_head_batch(hb, np_head, st));
     }
-    if (batch_heads) TIMED(KC_HEAD, launch_head_batch(hb, np_head, st));
     return finish_dbg();
   }
 
@@ -645,45 +671,13 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   hipStream_t st = (hipStream_t)stream;
   const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
-  const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
+  const int Tp = (Tq + 31) / 32 * 32, D = c.d_model;
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * D : nullptr;
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
-  auto qkv_args = [&](const PackedLayer& L) {
-    return QkvArgs{x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
-  };
-  auto stage1 = [&](const PackedLayer& L) {
-    return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
-                    L.ffn1_w1f8, L.ffn1_w2f8, 0.5f, nullptr};
-  };
-  const int l0 = group * c.layers_per_exit, l1 = l0 + c.layers_per_exit;
-  {
-    ChainArgs ca{};
-    ca.x = x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
-    ca.st[0] = stage1(enc->layers[l0]);
-    ca.qkv = qkv_args(enc->layers[l0]);
-    TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, np_o, false, true, false, st));
-  }
-  for (int li = l0; li < l1; ++li) {
-    const PackedLayer& L = enc->layers[li];
-    const bool last = li + 1 == l1;
-    AttnArgs at{ws.q, ws.k, ws.vt, key_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
-    TIMED(KC_ATTN, launch_attention(at, np_o, st));
-    ProjResArgs pr{x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
-    GluArgs ga{x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
-    TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
-    ChainArgs ca{};
-    ca.x = x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
-    ca.dw = DwArgs{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-    ca.pw2 = ProjResArgs{x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
-    ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
-                        L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, nullptr};
-    if (!last) {
-      ca.st[1] = stage1(enc->layers[li + 1]);
-      ca.qkv = qkv_args(enc->layers[li + 1]);
-    }
-    TIMED(KC_CHAIN, launch_ffn_chain(ca, np_ffn, np_o, np_o, true, !last, false, st));
-  }
-  return 0;
+  const LayerBufs bufs{x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, key_len};
+  const LayerFormats nps{np_ffn, np_o, np_o, np_o, np_o};
+  const int l0 = group * c.layers_per_exit;
+  return run_layer_plan(enc, l0, l0 + c.layers_per_exit, bufs, B, Tq, nps, [](int) -> float* { return nullptr; }, st);
 }
 
 int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, float* x, void* stream) {
