@@ -227,8 +227,7 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
   auto k = attn_kernel<DH, NP>;
   constexpr int lds_max = AttnLds<DH>::TOTAL2;
   const int lds = a.vt_lo ? AttnLds<DH>::TOTAL2 : AttnLds<DH>::TOTAL;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
-  if (e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_lds((const void*)k, lds_max); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.Tq + 32 * kAttnWaves - 1) / (32 * kAttnWaves), a.H, a.B), dim3(kAttnThreads), lds, st, a);
   return hipGetLastError();
 }

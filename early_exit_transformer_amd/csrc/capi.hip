@@ -68,6 +68,7 @@ enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, K
 
 struct eec_encoder {
   eec_config cfg;
+  int device = -1;  // the HIP device the packed-weight arena lives on: every entry point must run with it current
   Arena arena;
   bool packed = false;
   bool has_stem = false, has_stem1 = false, has_heads = false;  // eec_encoder_pack may be given layers only (building-block use)
@@ -165,6 +166,16 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   w.enc_len = a.take<int>(B);
   w.bytes = align_up(a.off);
   return w;
+}
+
+// One device per encoder handle: the arena (and the caller's workspace) are plain device allocations, never peer-mapped.
+int check_device(const eec_encoder* enc) {
+  int dev = -1;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (dev != enc->device)
+    return fail(EEC_ERR_BAD_ARG, "encoder was created on device " + std::to_string(enc->device) + " but device " +
+                                     std::to_string(dev) + " is current (one handle per device; re-create it after a move)");
+  return 0;
 }
 
 int check_cfg(const eec_config& c) {
@@ -271,6 +282,10 @@ int eec_encoder_create(const eec_config* cfg, eec_encoder** out) {
   if (int rc = check_cfg(*cfg)) return rc;
   eec_encoder* enc = new eec_encoder();
   enc->cfg = *cfg;
+  if (hipError_t e = hipGetDevice(&enc->device); e != hipSuccess) {
+    delete enc;
+    return hip_fail(e, "hipGetDevice");
+  }
   enc->carve();  // dry run: sizes only
   const size_t need = enc->arena.off;
   void* mem = nullptr;
@@ -298,6 +313,7 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
   if (!enc || !p || !p->layers) return fail(EEC_ERR_BAD_ARG, "null argument");
   if ((p->head_w == nullptr) != (p->head_b == nullptr)) return fail(EEC_ERR_BAD_ARG, "head_w and head_b go together");
   if (enc->cfg.arch != EEC_ARCH_CONFORMER) return fail(EEC_ERR_BAD_ARG, "use eec_encoder_pack_legacy for EEC_ARCH_LEGACY");
+  if (int rc = check_device(enc)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const eec_config& c = enc->cfg;
   const int D = c.d_model, F = c.d_ff;
@@ -373,6 +389,7 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
   if (!enc || !p || !p->layers || !p->group_ln_w || !p->group_ln_b || !p->head_w || !p->head_b)
     return fail(EEC_ERR_BAD_ARG, "null argument");
   if (enc->cfg.arch != EEC_ARCH_LEGACY) return fail(EEC_ERR_BAD_ARG, "encoder was not created with EEC_ARCH_LEGACY");
+  if (int rc = check_device(enc)) return rc;
   hipStream_t st = (hipStream_t)stream;
   const eec_config& c = enc->cfg;
   const int D = c.d_model, F = c.d_ff;
@@ -448,6 +465,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   if (enc->packed && enc->cfg.arch == EEC_ARCH_CONFORMER && (!enc->has_stem || (out && !enc->has_heads)))
     return fail(EEC_ERR_NOT_PACKED, "this encoder was packed without stem / head parameters");
   if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
+  if (int rc = check_device(enc)) return rc;
   if (B <= 0 || T < 7) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 7 (two k=3 s=2 convs)");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
   const eec_config& c = enc->cfg;
@@ -660,6 +678,7 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
                               void* workspace, size_t workspace_bytes, void* stream) {
   if (!enc || !x || !key_len || !workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (!enc->packed) return fail(EEC_ERR_NOT_PACKED, "eec_encoder_pack has not been called");
+  if (int rc = check_device(enc)) return rc;
   const eec_config& c = enc->cfg;
   if (c.arch != EEC_ARCH_CONFORMER) return fail(EEC_ERR_UNSUPPORTED, "group forward is built for EEC_ARCH_CONFORMER");
   if (group < 0 || group >= c.n_exits) return fail(EEC_ERR_BAD_ARG, "group out of range");
@@ -683,6 +702,7 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
 int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, float* x, void* stream) {
   if (!enc || !mel || !x) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (!enc->packed || !enc->has_stem1) return fail(EEC_ERR_NOT_PACKED, "no packed stem parameters");
+  if (int rc = check_device(enc)) return rc;
   if (B <= 0 || T < 3) return fail(EEC_ERR_BAD_ARG, "need B > 0 and T >= 3");
   const eec_config& c = enc->cfg;
   const int T1 = (T - 3) / 2 + 1;
@@ -696,6 +716,7 @@ int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, 
 int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, float* out, int precision, void* stream) {
   if (!enc || !x || !out) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (!enc->packed || !enc->has_heads) return fail(EEC_ERR_NOT_PACKED, "no packed head parameters");
+  if (int rc = check_device(enc)) return rc;
   if (exit < 0 || exit >= enc->cfg.n_exits || M <= 0) return fail(EEC_ERR_BAD_ARG, "exit / M out of range");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
   HeadArgs h{x, M, enc->cfg.vocab, enc->head_p[exit], enc->head_b[exit], out};
@@ -708,6 +729,7 @@ int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* targe
                  int blank, float* nll_scratch, float* loss_per_exit, void* stream) {
   if (!logp || !targets || !target_len || !nll_scratch || !loss_per_exit) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (E <= 0 || B <= 0 || Tq <= 0 || V <= 0 || S <= 0) return fail(EEC_ERR_BAD_ARG, "bad size");
+  if (blank < 0 || blank >= V) return fail(EEC_ERR_BAD_ARG, "blank must be a label in [0, V)");
   if (2 * S + 1 > 512) return fail(EEC_ERR_UNSUPPORTED, "target length above 255");
   EEC_HIP(launch_ctc_loss(logp, (const long long*)targets, (const long long*)target_len, E, B, Tq, V, S, blank, nll_scratch,
                           loss_per_exit, (hipStream_t)stream));

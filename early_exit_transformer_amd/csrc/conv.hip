@@ -54,14 +54,8 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
 }
 
 hipError_t launch_dw_pw2(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
   auto k = np == 3 ? dw_pw2_kernel<3> : dw_pw2_kernel<1>;
-  bool& done = np == 3 ? d3 : d1;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kDwLds);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_max_lds((const void*)k, kDwLds); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(512), kDwLds, st, d, a);
   return hipGetLastError();
 }

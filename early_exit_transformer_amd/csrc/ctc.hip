@@ -31,7 +31,11 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
                                                        int S, int blank, float* __restrict__ nll) {
   const int lat = blockIdx.x, b = lat % B, lane = threadIdx.x;
   const float* lp = logp + (size_t)lat * Tq * V;
-  const int len = (int)target_len[b];
+  // inputs nn.CTCLoss validates on the host: a length outside [0, S] or a label outside [0, V) would index out of
+  // bounds.  Such a lattice is not run on the caller's data: its nll becomes NaN (ctc_reduce_kernel propagates it).
+  const long long len_raw = target_len[b];
+  bool bad = len_raw < 0 || len_raw > (long long)S;
+  const int len = bad ? 0 : (int)len_raw;
   const int L = 2 * len + 1;
   int label[P];
   bool skip_ok[P], live[P];
@@ -43,10 +47,13 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
     live[i] = s < L;
     if (s < L && (s & 1)) {
       const int k = s >> 1;
-      label[i] = (int)targets[(size_t)b * S + k];
-      skip_ok[i] = k > 0 && label[i] != (int)targets[(size_t)b * S + k - 1];
+      const long long lab = targets[(size_t)b * S + k];
+      if (lab < 0 || lab >= (long long)V) bad = true;
+      label[i] = (lab < 0 || lab >= (long long)V) ? blank : (int)lab;
+      skip_ok[i] = k > 0 && lab != targets[(size_t)b * S + k - 1];
     }
   }
+  bad = __any((int)bad) != 0;  // wave-uniform
   float livef[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
@@ -123,10 +130,13 @@ __global__ __launch_bounds__(64) void ctc_alpha_kernel(const float* __restrict__
     const int s = lane * P + i;
     if (s == L - 1 || s == L - 2) tail += alpha[i];
   }
+  bad = bad || __any((int)(tail != tail)) != 0;  // NaN log-probs that reach the final states (fmaxf / > drop NaNs silently)
   const int e_lane = tail > 0.f ? ex : kCtcEmpty;
   const int e_max = (int)wave_max((float)e_lane);  // exponents are small integers: exact in fp32
   const float total = wave_sum(tail > 0.f ? ldexpf(tail, max(e_lane - e_max, -200)) : 0.f);
-  if (lane == 0) nll[lat] = (total > 0.f) ? -(logf(total) + (float)e_max * 0.6931471805599453f) : INFINITY;
+  // a NaN emission makes `total` NaN: (NaN > 0) is false, so test it explicitly instead of reporting "infeasible"
+  if (lane == 0)
+    nll[lat] = (bad || total != total) ? __builtin_nanf("") : (total > 0.f) ? -(logf(total) + (float)e_max * 0.6931471805599453f) : INFINITY;
 }
 
 // loss_e = mean_b( zero_inf(nll[e][b]) / max(len_b, 1) ): fixed summation order (bitwise reproducible)
@@ -136,7 +146,7 @@ __global__ void ctc_reduce_kernel(const float* nll, const long long* target_len,
     float s = 0.f;
     for (int b = 0; b < B; ++b) {
       float v = nll[e * B + b];
-      if (isinf(v) || isnan(v)) v = 0.f;  // zero_infinity=True
+      if (isinf(v)) v = 0.f;  // zero_infinity=True zeroes infinite losses only: NaN (bad input) propagates
       const long long l = target_len[b] > 0 ? target_len[b] : 1;
       s += v / (float)l;
     }

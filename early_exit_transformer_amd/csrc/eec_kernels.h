@@ -4,6 +4,10 @@
 
 namespace eec {
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute is per device, so a
+// process-wide flag would leave the > 64 KiB launches of a second device failing.  Thread-safe.
+hipError_t ensure_max_lds(const void* kernel, int bytes);
+
 struct FfnArgs {
   float* x;  // [M][256] fp32, updated in place
   int M, F;

@@ -519,12 +519,7 @@ template <int NP, int ACT, int FNP, int QNP, int NS>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
   auto k = ffn_chain_kernel<NP, ACT, FNP, QNP, NS>;
   constexpr int lds = FNP != 0 ? (kDwLds > kFfnLds ? kDwLds : kFfnLds) : kFfnLds;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  if (hipError_t e = ensure_max_lds((const void*)k, lds); e != hipSuccess) return e;
   const int grid = (a.M + kTileRows - 1) / kTileRows;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), lds, st, a);
   return hipGetLastError();

@@ -30,18 +30,9 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   qkv_body<NP>(smem, a, row0, rq);
 }
 
-template <typename K>
-static hipError_t set_lds_once(K k, int bytes, bool& done) {
-  if (done) return hipSuccess;
-  hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  done = e == hipSuccess;
-  return e;
-}
-
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
   auto k = np == 3 ? qkv_kernel<3> : qkv_kernel<1>;
-  hipError_t e = set_lds_once(k, kLinLds, np == 3 ? d3 : d1);
+  hipError_t e = ensure_max_lds((const void*)k, kLinLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kLinLds, st, a);
   return hipGetLastError();
@@ -129,10 +120,9 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResAr
 #define EEC_PROJ_MT 1
 #endif
 hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
   constexpr int MT = EEC_PROJ_MT, ROWS = 32 * MT, LDS = 2 * ROWS * kALd;
   auto k = np == 3 ? proj_residual_kernel<3, MT> : proj_residual_kernel<1, MT>;
-  hipError_t e = set_lds_once(k, LDS, np == 3 ? d3 : d1);
+  hipError_t e = ensure_max_lds((const void*)k, LDS);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + ROWS - 1) / ROWS), dim3(kLinThreads), LDS, st, a);
   return hipGetLastError();
@@ -242,9 +232,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
 }
 
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
   auto k = np == 3 ? proj_glu_kernel<3> : proj_glu_kernel<1>;
-  hipError_t e = set_lds_once(k, kProjGluLds, np == 3 ? d3 : d1);
+  hipError_t e = ensure_max_lds((const void*)k, kProjGluLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kProjGluLds, st, a, g);
   return hipGetLastError();
@@ -304,9 +293,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void head_batch_kernel(HeadBatchArg
 }
 
 hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
-  static bool d3 = false, d1 = false;
   auto k = np == 3 ? head_kernel<3> : head_kernel<1>;
-  hipError_t e = set_lds_once(k, kHeadLds, np == 3 ? d3 : d1);
+  hipError_t e = ensure_max_lds((const void*)k, kHeadLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows), dim3(kLinThreads), kHeadLds, st, a);
   return hipGetLastError();
@@ -314,9 +302,8 @@ hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
 
 hipError_t launch_head_batch(const HeadBatchArgs& a, int np, hipStream_t st) {
   if (a.E < 1 || a.E > kMaxHeadExits) return hipErrorInvalidValue;
-  static bool d3 = false, d1 = false;
   auto k = np == 3 ? head_batch_kernel<3> : head_batch_kernel<1>;
-  hipError_t e = set_lds_once(k, kHeadLds, np == 3 ? d3 : d1);
+  hipError_t e = ensure_max_lds((const void*)k, kHeadLds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + kTileRows - 1) / kTileRows, a.E), dim3(kLinThreads), kHeadLds, st, a);
   return hipGetLastError();

@@ -1,7 +1,25 @@
 // Weight packing, length conversion and greedy CTC decode.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "eec_kernels.h"
 
 namespace eec {
+
+hipError_t ensure_max_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, int> done;  // (kernel, device) -> bytes already granted
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = done.find({kernel, dev});
+  if (it != done.end() && it->second >= bytes) return hipSuccess;
+  e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done[{kernel, dev}] = bytes;
+  return e;
+}
 
 // W[N][K] fp32 (torch Linear / 1x1-conv layout) -> MFMA fragments, hi and lo fp16 planes.
 // out[((nt*KS + s)*2 + plane)*64 + lane] = 8 halves W[32nt + (lane&31)][16s + 8(lane>>5) + j]

@@ -177,20 +177,10 @@ hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st) {
   const int K1 = a.n_mels * 3;
   if (K1 % 16 || K1 > 384) return hipErrorInvalidValue;
   const int lds1 = 2 * kTileRows * (K1 + 8) * 2;
-  static bool d1[2] = {false, false}, d2[2] = {false, false};
   auto k1 = np == 3 ? stem_conv1_kernel<3, false> : stem_conv1_kernel<1, false>;
   auto k2 = np == 3 ? stem_conv2_kernel<3> : stem_conv2_kernel<1>;
-  const int v = np == 3;
-  if (!d1[v]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileRows * (384 + 8) * 2);
-    if (e != hipSuccess) return e;
-    d1[v] = true;
-  }
-  if (!d2[v]) {
-    hipError_t e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, kStem2Lds);
-    if (e != hipSuccess) return e;
-    d2[v] = true;
-  }
+  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kTileRows * (384 + 8) * 2); e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_lds((const void*)k2, kStem2Lds); e != hipSuccess) return e;
   const int M1 = a.B * a.T1;
   hipLaunchKernelGGL(k1, dim3((M1 + kTileRows - 1) / kTileRows), dim3(kStemThreads), lds1, st, a);
   hipError_t e = hipGetLastError();
@@ -203,13 +193,8 @@ hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st) {
 hipError_t launch_subsample_single(const SubsampleArgs& a, hipStream_t st) {
   const int K1 = a.n_mels * 3;
   if (K1 % 16 || K1 > 384) return hipErrorInvalidValue;
-  static bool done = false;
   auto k1 = stem_conv1_kernel<3, true>;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTileRows * (384 + 8) * 2);
-    if (e != hipSuccess) return e;
-    done = true;
-  }
+  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kTileRows * (384 + 8) * 2); e != hipSuccess) return e;
   const int M1 = a.B * a.T1;
   hipLaunchKernelGGL(k1, dim3((M1 + kTileRows - 1) / kTileRows), dim3(kStemThreads), 2 * kTileRows * (K1 + 8) * 2, st, a);
   return hipGetLastError();

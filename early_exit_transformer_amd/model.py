@@ -70,6 +70,7 @@ class _HipEncoderMixin:
         self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len,
                                    capi.ARCH_CONFORMER)
         self._enc = None
+        self._enc_device = None
         self._packed_key = None
         self._ws: Dict[Tuple[int, int, int], Tensor] = {}
         self._gws: Dict[Tuple[int, int, int], Tensor] = {}  # workspaces of the group-level entry points
@@ -95,10 +96,16 @@ class _HipEncoderMixin:
         if self._enc is not None and key == self._packed_key:
             return
         lib = capi.load()
+        if self._enc is not None and self._enc_device != device:
+            # model.to(another device): the packed-weight arena lives on the old device (one handle per device, eec.h)
+            lib.eec_encoder_destroy(self._enc)
+            self._enc, self._packed_key = None, None
+            self._ws.clear()
+            self._gws.clear()
         if self._enc is None:
             h = C.c_void_p()
             capi.check(lib.eec_encoder_create(C.byref(self._cfg), C.byref(h)), "eec_encoder_create")
-            self._enc = h
+            self._enc, self._enc_device = h, device
         sd = {k: v for k, v in self.state_dict(keep_vars=True).items()}
 
         def ptr(name: str) -> int:
@@ -286,6 +293,7 @@ class Splitformer(Early_conformer):
         self._par_cfg = capi.EecConfig(d_model, n_head, d_feed_forward, depthwise_kernel_size, 2, 1, features_length,
                                        dec_voc_size, max_len, capi.ARCH_CONFORMER)
         self._par_enc = None
+        self._par_device = None
         self._par_key = None
 
     def __del__(self):
@@ -303,10 +311,13 @@ class Splitformer(Early_conformer):
         if self._par_enc is not None and key == self._par_key:
             return
         lib = capi.load()
+        if self._par_enc is not None and self._par_device != device:
+            lib.eec_encoder_destroy(self._par_enc)
+            self._par_enc, self._par_key = None, None
         if self._par_enc is None:
             h = C.c_void_p()
             capi.check(lib.eec_encoder_create(C.byref(self._par_cfg), C.byref(h)), "eec_encoder_create")
-            self._par_enc = h
+            self._par_enc, self._par_device = h, device
         sd = dict(self.state_dict(keep_vars=True))
 
         def ptr(name: str) -> int:

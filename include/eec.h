@@ -10,6 +10,12 @@
  * void*.  Every function returns 0 on success, a non-zero hipError_t / EEC_ERR_* code
  * otherwise; eec_last_error() returns a thread-local message.  No entry point allocates,
  * frees or synchronises the device except create/destroy/pack.
+ *
+ * Devices: an eec_encoder handle belongs to the HIP device that was current in eec_encoder_create (its packed-weight
+ * arena is a plain allocation on that device).  Every later call on the handle must be made with the same device
+ * current and with parameters / inputs / workspace on it, else EEC_ERR_BAD_ARG.  The intended deployment is one
+ * process per GPU (torch.distributed over RCCL); a process that does drive several devices creates one handle per
+ * device (launch attributes are tracked per device).  Handles are not thread-safe; use one per thread or lock.
  */
 #ifndef EEC_H_
 #define EEC_H_
@@ -183,7 +189,10 @@ int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32
  * nn.CTCLoss(blank, reduction='mean', zero_infinity=True), train.py:259), all exits and utterances in one launch:
  *   logp [E, B, T', V] fp32 log-probs (the encoder output as is; input length = T' for every utterance)
  *   targets [B, S] int64, target_len [B] int64 (device copies of the caller's tensors; len <= 255)
- *   nll_scratch [E*B] fp32, loss_per_exit [E] fp32 = batch mean of nll / max(len, 1); train.py's loss = their sum. */
+ *   nll_scratch [E*B] fp32, loss_per_exit [E] fp32 = batch mean of nll / max(len, 1); train.py's loss = their sum.
+ * Input checking (nn.CTCLoss raises on these; a kernel cannot): a target_len outside [0, S] or a label outside [0, V)
+ * among an utterance's first target_len labels makes that utterance's nll -- and the exit's loss -- NaN; NaN log-probs
+ * propagate as NaN; only +inf (an infeasible alignment) is zeroed, as zero_infinity=True does. */
 int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
                  int blank, float* nll_scratch, float* loss_per_exit, void* stream);
 

@@ -123,3 +123,42 @@ def test_world2_gloo_sharded_exit_loss_equals_global_batch():
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
     assert combined == pytest.approx(full, rel=2e-5, abs=2e-5)
+
+
+def _run_bench(extra_env, *argv):
+    import subprocess
+    import sys
+    env = dict(os.environ, EEC_BENCH_PLUMBING="1", **extra_env)
+    env.pop("WORLD_SIZE", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True,
+                          timeout=300)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` (no torchrun): the parent starts N rank processes itself, relays rank 0's ONE JSON line
+    and the ranks really exchanged data (the combined value is the B-weighted mean of both ranks' inputs)."""
+    import json
+    res = _run_bench({}, "--gpus", "2", "--steps", "2", "--batch", "64")
+    assert res.returncode == 0, res.stderr
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["plumbing"] is True
+    want = [(e * 64 + (e + 1) * 65) / 129.0 for e in range(6)]  # rank r holds exit values e + r with B_r = 64 + r
+    assert rec["combined"] == pytest.approx(want, rel=1e-6)
+
+
+def test_bench_launcher_propagates_a_failed_rank():
+    res = _run_bench({"EEC_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "1")
+    assert res.returncode == 7
+    assert "rank 1 exited with status 7" in res.stderr
+
+
+def test_bench_parent_makes_no_gpu_call_before_spawning():
+    """The launcher branch must come before anything that initialises HIP (torch.cuda.*), or the ranks inherit a
+    process that already owns the device."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    main = src[src.index("def main():"):]
+    assert main.index("launch_ranks(args.gpus") < main.index("torch.cuda.")
+    launcher = src[src.index("def launch_ranks"):src.index("def plumbing_check")]
+    assert "torch.cuda" not in launcher and "import torch" not in launcher
