@@ -61,7 +61,7 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
            "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy",
            "eec_encoder_forward_prefix", "eec_encoder_group_workspace_bytes", "eec_encoder_group_forward",
-           "eec_encoder_head_forward", "eec_encoder_stem1_forward"]
+           "eec_encoder_head_forward", "eec_encoder_stem1_forward", "eec_encoder_lengths"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -97,6 +97,7 @@ def load() -> C.CDLL:
                                               C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_encoder_head_forward.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
     lib.eec_encoder_stem1_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.eec_encoder_lengths.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.eec_greedy_ctc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p]
     lib.eec_ctc_loss.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
   const int q = q0 + r;
   if (q < a.Tq) {
-    const size_t rowoff = ((size_t)b * a.Tq + q) * kD + hd * DH;
+    const size_t rowoff = ((size_t)b * a.Tq + q) * (a.H * DH) + hd * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll

@@ -64,6 +64,7 @@ size_t f8_u4(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 63) / 64) * 
 
 }  // namespace
 
+constexpr int kMaxStem1Batch = 4096;
 enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, KC_DW_PW2, KC_HEAD, KC_CHAIN, KC_COUNT };
 
 struct eec_encoder {
@@ -82,6 +83,7 @@ struct eec_encoder {
   std::vector<PackedLayer> layers;
   uint4 *sub_w1p, *sub_w2p;
   float *sub_b1, *sub_b2, *pe;
+  int* stem_e;  // [kMaxStem1Batch] per-utterance scale exponents of eec_encoder_stem1_forward (the full forward keeps its own in the workspace)
   std::vector<uint4*> head_p;
   std::vector<float*> head_b;
 
@@ -127,6 +129,7 @@ struct eec_encoder {
     sub_w2p = arena.take<uint4>(frag_u4(D, 3 * D));
     sub_b2 = arena.take<float>(D);
     pe = arena.take<float>((size_t)cfg.max_len * D);
+    stem_e = arena.take<int>(kMaxStem1Batch);
     head_p.assign(cfg.n_exits, nullptr);
     head_b.assign(cfg.n_exits, nullptr);
     for (int e = 0; e < cfg.n_exits; ++e) {
@@ -143,7 +146,7 @@ struct Workspace {
   float* x;
   float* y;  // [(E-1)][M][256]: exit rows for the batched head launch when the caller passes no tap buffer
   half_t *mid_hi, *mid_lo, *q, *k, *vt, *p_hi, *p_lo, *g;
-  int* enc_len;
+  int *enc_len, *mel_e;
   size_t bytes;
 };
 
@@ -164,6 +167,7 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   w.p_lo = a.take<half_t>(M * D);
   w.g = a.take<half_t>(M * D);
   w.enc_len = a.take<int>(B);
+  w.mel_e = a.take<int>(B);
   w.bytes = align_up(a.off);
   return w;
 }
@@ -180,9 +184,9 @@ int check_device(const eec_encoder* enc) {
 
 int check_cfg(const eec_config& c) {
   if (c.arch != EEC_ARCH_CONFORMER && c.arch != EEC_ARCH_LEGACY) return fail(EEC_ERR_BAD_ARG, "unknown arch");
-  if (c.d_model != kD) return fail(EEC_ERR_UNSUPPORTED, "d_model must be 256 in this build");
-  if (c.n_heads <= 0 || kD % c.n_heads) return fail(EEC_ERR_BAD_ARG, "n_heads must divide d_model");
-  const int dh = kD / c.n_heads;
+  if (c.d_model != 256 && c.d_model != 512) return fail(EEC_ERR_UNSUPPORTED, "d_model must be 256 or 512 in this build");
+  if (c.n_heads <= 0 || c.d_model % c.n_heads) return fail(EEC_ERR_BAD_ARG, "n_heads must divide d_model");
+  const int dh = c.d_model / c.n_heads;
   if (dh != 32 && dh != 64) return fail(EEC_ERR_UNSUPPORTED, "head dim must be 32 or 64");
   if (c.d_ff <= 0 || c.d_ff % 32) return fail(EEC_ERR_UNSUPPORTED, "d_ff must be a positive multiple of 32");
   if (c.arch == EEC_ARCH_CONFORMER && (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1)))
@@ -229,7 +233,7 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
   const eec_config& c = enc->cfg;
   const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
   auto qkv_args = [&](const PackedLayer& L) {
-    return QkvArgs{b.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo};
+    return QkvArgs{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo};
   };
   auto stage1 = [&](const PackedLayer& L) {
     return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
@@ -237,7 +241,7 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
   };
   {
     ChainArgs ca{};
-    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.nstage = 1;
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = 1;
     ca.st[0] = stage1(enc->layers[l0]);
     ca.qkv = qkv_args(enc->layers[l0]);
     TIMED(KC_CHAIN, launch_ffn_chain(ca, np.ffn, np.front, np.qkv, false, true, false, st));
@@ -247,13 +251,13 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     const bool last = li + 1 == l1;
     AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
     TIMED(KC_ATTN, launch_attention(at, np.att, st));
-    ProjResArgs pr{b.x, M, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b};
+    ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b};
     GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g};
     TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
     ChainArgs ca{};
-    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.nstage = last ? 1 : 2;
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = last ? 1 : 2;
     ca.dw = DwArgs{b.g, B, Tq, L.dw_wfold, L.dw_bfold, b.p_hi, b.p_lo};
-    ca.pw2 = ProjResArgs{b.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+    ca.pw2 = ProjResArgs{b.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
     ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
                         L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap_of(li)};
     if (!last) {
@@ -275,6 +279,12 @@ int eec_out_frames(int T) {
   if (T < 7) return 0;
   const int T1 = (T - 3) / 2 + 1;
   return (T1 - 3) / 2 + 1;
+}
+
+int eec_encoder_lengths(const int64_t* lengths, int B, int Tq, int32_t* enc_len, void* stream) {
+  if (!lengths || !enc_len || B <= 0 || Tq <= 0) return fail(EEC_ERR_BAD_ARG, "bad argument");
+  EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, enc_len, (hipStream_t)stream));
+  return 0;
 }
 
 int eec_encoder_create(const eec_config* cfg, eec_encoder** out) {
@@ -346,7 +356,7 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(launch_pack_frags(s.conv_pw1_w, 2 * D, D, L.conv_pw1_p, 1.0f, st));
     EEC_HIP(launch_pack_frags(s.conv_pw2_w, D, D, L.conv_pw2_p, 1.0f, st));
     EEC_HIP(launch_fold_dw(s.conv_dw_w, s.conv_dw_b, s.conv_bn_w, s.conv_bn_b, s.conv_bn_rm, s.conv_bn_rv,
-                           c.dw_kernel, L.dw_wfold, L.dw_bfold, st));
+                           c.dw_kernel, D, L.dw_wfold, L.dw_bfold, st));
     EEC_HIP(cp(L.ffn2_ln_w, s.ffn2_ln_w, D));
     EEC_HIP(cp(L.ffn2_ln_b, s.ffn2_ln_b, D));
     EEC_HIP(launch_scale_copy(s.ffn2_b1, L.ffn2_b1, F, kLog2e, st));
@@ -396,7 +406,7 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
   auto cp = [&](float* dst, const float* src, size_t n) {
     return hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st);
   };
-  const size_t tile8 = (size_t)8 * (D / 16) * 128;  // 8 n-tiles (256 output columns) of a K=256 fragment matrix
+  const size_t tile8 = (size_t)(D / 32) * (D / 16) * 128;  // the D/32 n-tiles (D output columns) of one of w_q / w_k / w_v
   for (size_t i = 0; i < enc->layers.size(); ++i) {
     const eec_legacy_layer_params& s = p->layers[i];
     PackedLayer& L = enc->layers[i];
@@ -501,7 +511,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   {
-    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
+    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, D, ws.mel_e, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
     TIMED(KC_STEM, launch_subsample(a, 3, st));  // raw power mel: always hi/lo split (1 % of the flops)
   }
   ++step;
@@ -514,18 +524,18 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       for (int l = 0; l < c.layers_per_exit; ++l) {
         const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
         {
-          QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
+          QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
           TIMED(KC_QKV, launch_qkv(a, np_o, st));
           AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
           TIMED(KC_ATTN, launch_attention(at, np_o, st));
-          ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+          ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
           TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
         }
         ++step;
         if (done()) return finish_dbg();
         {
           const bool last = l == c.layers_per_exit - 1;  // Encoder.layer_norm closes the group
-          FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2,
+          FfnArgs a{ws.x, M, c.d_ff, D, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2,
                     last ? L.final_ln_w : nullptr, last ? L.final_ln_b : nullptr, 1.0f, true};
           a.w1f8 = L.ffn2_w1f8, a.w2f8 = L.ffn2_w2f8;
           TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
@@ -534,7 +544,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
         if (done()) return finish_dbg();
       }
       if (out) {
-        HeadArgs h{ws.x, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+        HeadArgs h{ws.x, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
         TIMED(KC_HEAD, launch_head(h, np_o, st));
       }
       if (taps_opt)
@@ -559,14 +569,14 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
     if (int rc = run_layer_plan(enc, 0, n_layers, bufs, B, Tq, nps, tap_of, st)) return rc;
     if (out) {
       HeadBatchArgs hb{};
-      hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = n_groups;
+      hb.out = out, hb.M = M, hb.V = c.vocab, hb.E = n_groups, hb.D = D;
       for (int e = 0; e < n_groups; ++e) {
         const int li = (e + 1) * c.layers_per_exit - 1;
         const float* rows = li + 1 == n_layers ? ws.x : tap_of(li);
         if (batch_heads) {
           hb.x[e] = rows, hb.wp[e] = enc->head_p[e], hb.bias[e] = enc->head_b[e];
         } else {
-          HeadArgs h{rows, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+          HeadArgs h{rows, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
           TIMED(KC_HEAD, launch_head(h, np_head, st));
         }
       }
@@ -579,18 +589,18 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
     for (int l = 0; l < c.layers_per_exit; ++l) {
       const PackedLayer& L = enc->layers[e * c.layers_per_exit + l];
       {
-        FfnArgs a{ws.x, M, c.d_ff, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr};
+        FfnArgs a{ws.x, M, c.d_ff, D, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr};
         a.w1f8 = L.ffn1_w1f8, a.w2f8 = L.ffn1_w2f8;
         TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
       ++step;
       if (done()) return finish_dbg();
       {
-        QkvArgs a{ws.x, M, B, Tq, Tp, H, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
+        QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
         TIMED(KC_QKV, launch_qkv(a, np_o, st));
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
-        ProjResArgs pr{ws.x, M, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
+        ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
         GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
         // out-proj + residual and the conv module's LN -> pointwise-1 -> GLU share one launch
         // (the sub-step hook stops between them, so it falls back to the two separate kernels)
@@ -605,13 +615,13 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       }
       {
         DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-        ProjResArgs pr{ws.x, M, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+        ProjResArgs pr{ws.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
         TIMED(KC_DW_PW2, launch_dw_pw2(da, pr, np_o, st));
       }
       ++step;
       if (done()) return finish_dbg();
       {
-        FfnArgs a{ws.x, M, c.d_ff, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b};
+        FfnArgs a{ws.x, M, c.d_ff, D, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b};
         a.w1f8 = L.ffn2_w1f8, a.w2f8 = L.ffn2_w2f8;
         TIMED(KC_FFN, launch_ffn(a, np_ffn, st));
       }
@@ -619,7 +629,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (done()) return finish_dbg();
     }
     if (out) {
-      HeadArgs h{ws.x, M, c.vocab, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+      HeadArgs h{ws.x, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
       TIMED(KC_HEAD, launch_head(h, np_o, st));
     }
     if (taps_opt)
@@ -708,7 +718,8 @@ int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, 
   const int T1 = (T - 3) / 2 + 1;
   if (T1 > c.max_len) return fail(EEC_ERR_BAD_ARG, "T1 exceeds the positional-encoding table (max_len)");
   hipStream_t st = (hipStream_t)stream;
-  SubsampleArgs a{mel, B, c.n_mels, T, T1, T1, enc->sub_w1p, enc->sub_b1, nullptr, nullptr, enc->pe, nullptr, nullptr, x};
+  if (B > kMaxStem1Batch) return fail(EEC_ERR_UNSUPPORTED, "stem1: batch above 4096");
+  SubsampleArgs a{mel, B, c.n_mels, T, T1, T1, c.d_model, enc->stem_e, enc->sub_w1p, enc->sub_b1, nullptr, nullptr, enc->pe, nullptr, nullptr, x};
   TIMED(KC_STEM, launch_subsample_single(a, st));
   return 0;
 }
@@ -719,7 +730,7 @@ int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, 
   if (int rc = check_device(enc)) return rc;
   if (exit < 0 || exit >= enc->cfg.n_exits || M <= 0) return fail(EEC_ERR_BAD_ARG, "exit / M out of range");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
-  HeadArgs h{x, M, enc->cfg.vocab, enc->head_p[exit], enc->head_b[exit], out};
+  HeadArgs h{x, M, enc->cfg.vocab, enc->cfg.d_model, enc->head_p[exit], enc->head_b[exit], out};
   hipStream_t st = (hipStream_t)stream;
   TIMED(KC_HEAD, launch_head(h, precision == EEC_PREC_F16 ? 1 : 3, st));
   return 0;

@@ -2,10 +2,11 @@
 //
 // Conventions used by every kernel in this directory
 // ---------------------------------------------------
-// * A "row tile" is 64 consecutive rows of the flattened (utterance x frame)
-//   axis M = B*T'.  One 512-thread workgroup (8 waves, two per SIMD) owns one
-//   row tile and all of the output columns of it; M/64 = 256 tiles at the
-//   headline shape = one workgroup per CU.
+// * A "row tile" is Geo<D>::kRows consecutive rows of the flattened (utterance x frame)
+//   axis M = B*T': 64 rows at d_model 256, 32 rows at d_model 512 (the tile's activation
+//   planes are 64 KiB of LDS either way).  One 512-thread workgroup (8 waves, two per SIMD)
+//   owns one row tile and all of the output columns of it; at the headline shape (D = 256)
+//   M/64 = 256 tiles = one workgroup per CU.
 // * 16-bit operands are fp16.  "NP" = number of MFMA passes per product:
 //     NP=1  a_hi*w_hi                                   (plain fp16 operands)
 //     NP=3  a_hi*w_hi + a_hi*w_lo + a_lo*w_hi           (hi/lo split, ~2^-21)
@@ -39,20 +40,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kWave = 64;
-constexpr int kTileRows = 64;      // rows of M per workgroup
-constexpr int kThreads = 256;      // 4 waves
-constexpr int kD = 256;            // d_model this build is specialised for
 constexpr float kLnEps = 1e-5f;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kHalfMax = 65504.0f;
 
-// LDS geometry (bytes).  Row pads of one 16-B slot make ds_read_b128 of
-// "32 different rows, same column" conflict-free (stride = 4 banks mod 64).
-constexpr int kALd = (kD + 8) * 2;            // 528  : [64][256] fp16 activation plane
-constexpr int kAPlane = kTileRows * kALd;     // 33792
-constexpr int kA8Ld = kD + 16;                // 272  : [64][256] e5m2 byte plane (NP == 8), row pad keeps b128 reads conflict-free
-constexpr int kELd = (kD + 4) * 4;            // 1040 : [64][256] fp32 epilogue tile
-constexpr int kETile = kTileRows * kELd;      // 66560 (aliases the two A planes: 67584)
+// Tile geometry by d_model.  D = 256: 64-row tiles, a wave owns ONE 32-wide column tile of a D-wide output and two
+// 32-row tiles (acc[2][1]); D = 512: 32-row tiles, a wave owns TWO adjacent column tiles and one row tile (acc[1][2]).
+// LDS geometry in bytes; row pads of one 16-B slot make ds_read_b128 of "32 different rows, same column"
+// conflict-free (stride = 4 banks mod 64).
+template <int D>
+struct Geo {
+  static_assert(D == 256 || D == 512, "d_model must be 256 or 512");
+  static constexpr int kRows = 16384 / D;       // rows of M per workgroup: 64 / 32
+  static constexpr int kMT = kRows / 32;        // 32-row MFMA tiles per workgroup: 2 / 1
+  static constexpr int kNW = D / 256;           // 32-wide column tiles of a D-wide output per wave (8 waves): 1 / 2
+  static constexpr int kKS = D / 16;            // k-steps of a K = D product
+  static constexpr int kQ = D / 256;            // float4 pieces of a row per lane (piece q = columns 256 q + 4 lane ..)
+  static constexpr int kRPW = kRows / 8;        // rows per wave in a row pass: 8 / 4
+  static constexpr int kALd = (D + 8) * 2;      // 528 / 1040 : [rows][D] fp16 activation plane
+  static constexpr int kAPlane = kRows * kALd;  // 33792 / 33280
+  static constexpr int kA8Ld = D + 16;          // 272 / 528  : [rows][D] e5m2 byte plane (NP == 8)
+  static constexpr int kELd = (D + 4) * 4;      // 1040 / 2064: [rows][D] fp32 exchange tile
+  static constexpr int kETile = kRows * kELd;   // 66560 / 66048
+};
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
@@ -266,8 +276,8 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_l
 }
 
 // Same product with a runtime k-step count and no ring (ragged tails only).
-template <int NP, int NT, bool SWAP>
-__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+template <int NP, int NT, bool SWAP, int MT = 2>
+__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
                                            const uint4* __restrict__ w_lane, size_t nt_stride, int ks) {
   for (int s = 0; s < ks; ++s) {
 #pragma unroll
@@ -276,7 +286,7 @@ __device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][NT], const char* a_l
       h8 bl = bh;
       if (NP == 3) bl = __builtin_bit_cast(h8, w_lane[nt * nt_stride + (size_t)s * 128 + 64]);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
         if (NP == 3) {
           const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
@@ -289,32 +299,39 @@ __device__ __forceinline__ void gemm_plain(f32x16 (&acc)[2][NT], const char* a_l
   }
 }
 
-// Ring-pipelined product with a RUNTIME k-step count (swapped orientation, NT = 1): the loop is
+// Ring-pipelined product with a RUNTIME k-step count (swapped orientation): the loop is
 // unrolled by PF so ring slots stay statically indexed.  The ring must hold steps 0..PF-1.
-template <int NP, int PF>
-__device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][1], const char* a_lane, int ld_bytes, int plane_bytes,
-                                                const uint4* __restrict__ w_lane, int ks, WRing<NP, PF, 1>& r) {
+template <int NP, int PF, int NT = 1>
+__device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                                const uint4* __restrict__ w_lane, size_t nt_stride, int ks, WRing<NP, PF, NT>& r) {
   constexpr int LO = (NP == 3) ? 1 : 0;
   for (int s0 = 0; s0 < ks; s0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
       const int s = s0 + p;
       if (s < ks) {
-        const h8 bh = __builtin_bit_cast(h8, r.q[p][0][0]);
-        const h8 bl = __builtin_bit_cast(h8, r.q[p][0][LO]);
+        h8 ah[2], al[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          const h8 ah = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
-          if (NP == 3) {
-            const h8 al = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
-            acc[mt][0] = mfma16(bh, al, acc[mt][0]);
-            acc[mt][0] = mfma16(bl, ah, acc[mt][0]);
-          }
-          acc[mt][0] = mfma16(bh, ah, acc[mt][0]);
+          ah[mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + s * 32);
+          if (NP == 3) al[mt] = *(const h8*)(a_lane + plane_bytes + mt * 32 * ld_bytes + s * 32);
         }
-        if (s + PF < ks) {
-          r.q[p][0][0] = w_lane[(size_t)(s + PF) * 128];
-          if (NP == 3) r.q[p][0][LO] = w_lane[(size_t)(s + PF) * 128 + 64];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const h8 bh = __builtin_bit_cast(h8, r.q[p][nt][0]);
+          const h8 bl = __builtin_bit_cast(h8, r.q[p][nt][LO]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            if (NP == 3) {
+              acc[mt][nt] = mfma16(bh, al[mt], acc[mt][nt]);
+              acc[mt][nt] = mfma16(bl, ah[mt], acc[mt][nt]);
+            }
+            acc[mt][nt] = mfma16(bh, ah[mt], acc[mt][nt]);
+          }
+          if (s + PF < ks) {
+            r.q[p][nt][0] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128];
+            if (NP == 3) r.q[p][nt][LO] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128 + 64];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -386,18 +403,18 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 // NW: number of lo8 group buffers.  NW == NG: the whole stage is resident (loaded by the caller one stage ahead);
 // NW < NG: rolling buffers, group g lives in wg[g % NW] and is refilled with group g + NW right after its use
 // (the caller preloads groups 0 .. NW-1 of the next stage).
-template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0>
-__device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0, int MT = 2>
+__device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
                                              int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
                                              WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side()) {
   constexpr int KS = 4 * NG;
   auto hi_addr = [&](int s) { return (size_t)(s >> 2) * kF8Rec + (size_t)(s & 3) * 64; };
-  h8 ah[2][2];
+  h8 ah[2][MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
-  uint2 a8[2][4];   // [mt][step in group]: e5m2 of the activation hi fragments
+  for (int mt = 0; mt < MT; ++mt) ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
+  uint2 a8[MT][4];  // [mt][step in group]: e5m2 of the activation hi fragments
   uint2 w8[NT][4];  // [nt][step in group]: e5m2 of the weight hi fragments
-  i32x8 alo[2];     // activation lo8 of the current group
+  i32x8 alo[MT];    // activation lo8 of the current group
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int cur = s & 1, nxt = cur ^ 1, q = s & 3, g = s >> 2;
@@ -407,7 +424,7 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
     if (s + 1 < KS) {
 #endif
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
+      for (int mt = 0; mt < MT; ++mt) ah[nxt][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes + (s + 1) * 32);
     }
 #ifdef EEC_ABLATE_A
     if (s == 0) {
@@ -415,7 +432,7 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
     if (q == 0) {
 #endif
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         const uint4 l0 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64);
         const uint4 l1 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64 + 16);
         alo[mt] = (i32x8){(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
@@ -423,14 +440,14 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) a8[mt][q] = top_bytes(__builtin_bit_cast(uint4, ah[cur][mt]));
+    for (int mt = 0; mt < MT; ++mt) a8[mt][q] = top_bytes(__builtin_bit_cast(uint4, ah[cur][mt]));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const uint4 wq = r.q[s % PF][nt][0];
       w8[nt][q] = top_bytes(wq);
       const h8 bh = __builtin_bit_cast(h8, wq);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
         acc[mt][nt] = SWAP ? mfma16(bh, ah[cur][mt], acc[mt][nt]) : mfma16(ah[cur][mt], bh, acc[mt][nt]);
     }
 #ifdef EEC_ABLATE_W
@@ -450,7 +467,7 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
         const i32x8 wlo = {(int)G.lo[nt][0].x, (int)G.lo[nt][0].y, (int)G.lo[nt][0].z, (int)G.lo[nt][0].w,
                            (int)G.lo[nt][1].x, (int)G.lo[nt][1].y, (int)G.lo[nt][1].z, (int)G.lo[nt][1].w};
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           const i32x8 ahi = {(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
                              (int)a8[mt][2].x, (int)a8[mt][2].y, (int)a8[mt][3].x, (int)a8[mt][3].y};
           // DROP (diagnostic builds only): bit 0 skips the activation-residual term, bit 1 the weight-residual term
@@ -468,7 +485,7 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[2][NT], const char* a
     side(s);
     if (SIDE_VALU > 0) {
 #pragma unroll
-      for (int i = 0; i < 2 * NT; ++i) {
+      for (int i = 0; i < MT * NT; ++i) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, SIDE_VALU, 0);
       }
@@ -490,6 +507,20 @@ __device__ __forceinline__ void ring_fill_f8(WRing<1, PF, NT>& r, const uint4* _
   __builtin_amdgcn_sched_barrier(0);
 }
 
+template <int I>
+struct IntTag {
+  static constexpr int value = I;
+};
+// f(IntTag<K0>{}), ..., f(IntTag<K1-1>{}): a loop whose index is a compile-time constant in the body (register arrays
+// indexed by it never fall back to scratch memory, whatever the unroller decides)
+template <int K0, int K1, typename F>
+__device__ __forceinline__ void static_range(F&& f) {
+  if constexpr (K0 < K1) {
+    f(IntTag<K0>{});
+    static_range<K0 + 1, K1>(f);
+  }
+}
+
 template <int MT, int NT>
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 #pragma unroll
@@ -501,12 +532,9 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[MT][NT]) {
 }
 
 // ---------------------------------------------------------------------------
-// Prologues: fill the [64][256] activation planes in LDS.
-// Each wave handles 16 rows; a row is one coalesced 1 KiB float4 load.
+// Prologues: fill the [rows][D] activation planes in LDS.
 // ---------------------------------------------------------------------------
-// x fp32 [M][256] -> (optional LayerNorm) -> hi/lo planes.
-// All RPW rows of a wave are loaded first and their reductions run as RPW independent,
-// interleaved DPP chains (6 dependent cross-lane adds per row, N rows in flight).
+// N wave-wide sums as N independent, interleaved DPP chains (6 dependent cross-lane adds each).
 template <int N>
 __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
 #pragma unroll
@@ -525,49 +553,95 @@ __device__ __forceinline__ void wave_sum_n(float (&v)[N]) {
   for (int i = 0; i < N; ++i) v[i] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[i]), 63));
 }
 
-// LayerNorm of N rows held as one float4 per lane per row (row = 256 columns over 64 lanes).
-template <int N>
-__device__ __forceinline__ void layer_norm_rows(float4 (&v)[N], const float4 g, const float4 bt) {
+// A row of D columns is held by a wave as Q = D / 256 float4 pieces per lane: piece q = columns [256 q + 4 lane, + 4).
+template <int Q>
+struct RowV {
+  float4 p[Q];
+};
+template <int D>
+__device__ __forceinline__ RowV<Geo<D>::kQ> load_row(const float* __restrict__ row_ptr, int lane) {
+  RowV<Geo<D>::kQ> r;
+#pragma unroll
+  for (int q = 0; q < Geo<D>::kQ; ++q) r.p[q] = ((const float4*)row_ptr)[q * 64 + lane];
+  return r;
+}
+template <int D>
+__device__ __forceinline__ void store_row(float* __restrict__ row_ptr, const RowV<Geo<D>::kQ>& r, int lane) {
+#pragma unroll
+  for (int q = 0; q < Geo<D>::kQ; ++q) ((float4*)row_ptr)[q * 64 + lane] = r.p[q];
+}
+template <int Q>
+__device__ __forceinline__ RowV<Q> zero_row() {
+  RowV<Q> r;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) r.p[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  return r;
+}
+
+// LayerNorm of N rows (row = D columns over 64 lanes).  The reductions of the N rows run as N independent,
+// interleaved DPP chains.
+template <int D, int N>
+__device__ __forceinline__ void layer_norm_rows(RowV<Geo<D>::kQ> (&v)[N], const RowV<Geo<D>::kQ>& g, const RowV<Geo<D>::kQ>& bt) {
+  constexpr int Q = Geo<D>::kQ;
   float s[N];
 #pragma unroll
-  for (int i = 0; i < N; ++i) s[i] = v[i].x + v[i].y + v[i].z + v[i].w;
-  wave_sum_n<N>(s);
-  float q[N];
-#pragma unroll
   for (int i = 0; i < N; ++i) {
-    const float mean = s[i] * (1.0f / kD);
-    v[i].x -= mean, v[i].y -= mean, v[i].z -= mean, v[i].w -= mean;
-    q[i] = v[i].x * v[i].x + v[i].y * v[i].y + v[i].z * v[i].z + v[i].w * v[i].w;
+    s[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) s[i] += v[i].p[q].x + v[i].p[q].y + v[i].p[q].z + v[i].p[q].w;
   }
-  wave_sum_n<N>(q);
+  wave_sum_n<N>(s);
+  float sq[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) {
-    const float rs = rsqrtf(q[i] * (1.0f / kD) + kLnEps);
-    v[i].x = v[i].x * rs * g.x + bt.x;
-    v[i].y = v[i].y * rs * g.y + bt.y;
-    v[i].z = v[i].z * rs * g.z + bt.z;
-    v[i].w = v[i].w * rs * g.w + bt.w;
+    const float mean = s[i] * (1.0f / D);
+    sq[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float4& t = v[i].p[q];
+      t.x -= mean, t.y -= mean, t.z -= mean, t.w -= mean;
+      sq[i] += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+  }
+  wave_sum_n<N>(sq);
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const float rs = rsqrtf(sq[i] * (1.0f / D) + kLnEps);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      float4& t = v[i].p[q];
+      t.x = t.x * rs * g.p[q].x + bt.p[q].x;
+      t.y = t.y * rs * g.p[q].y + bt.p[q].y;
+      t.z = t.z * rs * g.p[q].z + bt.p[q].z;
+      t.w = t.w * rs * g.p[q].w + bt.p[q].w;
+    }
   }
 }
 
-// N rows held as one float4 per lane per row (local rows rl0 .. rl0+N-1 of the tile) -> activation planes:
+// N rows (local rows rl0 .. rl0+N-1 of the tile) -> activation planes:
 // fp16 hi plane, plus the fp16 lo plane (NP == 3) or the permuted e5m2 lo byte plane (NP == 8).
 // Rows at or beyond M are written as zeros when zero_tail is set (a LayerNorm turns a zero row into beta).
-template <int NP, int N>
-__device__ __forceinline__ void rows_to_planes(char* lds_act, float4 (&v)[N], int rl0, int row0, int M, bool zero_tail,
+template <int D, int NP, int N>
+__device__ __forceinline__ void rows_to_planes(char* lds_act, RowV<Geo<D>::kQ> (&v)[N], int rl0, int row0, int M, bool zero_tail,
                                                int lane = lane_id()) {
+  using G = Geo<D>;
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const int rl = rl0 + i;
-    if (zero_tail && row0 + rl >= M) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(v[i].x, v[i].y), s1 = split2<(NP == 1 ? 1 : 3)>(v[i].z, v[i].w);
-    h4 hi, lo;
-    hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
-    *(h4*)(lds_act + rl * kALd + lane * 8) = hi;
-    if (NP == 3) *(h4*)(lds_act + kAPlane + rl * kALd + lane * 8) = lo;
-    if (NP == 8) {  // e5m2 bytes of the lo halves, permuted to the MX slot order
-      const uint2 lb = __builtin_bit_cast(uint2, lo);
-      *(unsigned*)(lds_act + kAPlane + rl * kA8Ld + lo8_pos(lane * 4)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+    if (zero_tail && row0 + rl >= M) v[i] = zero_row<G::kQ>();
+#pragma unroll
+    for (int q = 0; q < G::kQ; ++q) {
+      const float4 t = v[i].p[q];
+      const int col = q * 256 + lane * 4;
+      const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(t.x, t.y), s1 = split2<(NP == 1 ? 1 : 3)>(t.z, t.w);
+      h4 hi, lo;
+      hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+      *(h4*)(lds_act + rl * G::kALd + col * 2) = hi;
+      if (NP == 3) *(h4*)(lds_act + G::kAPlane + rl * G::kALd + col * 2) = lo;
+      if (NP == 8) {  // e5m2 bytes of the lo halves, permuted to the MX slot order
+        const uint2 lb = __builtin_bit_cast(uint2, lo);
+        *(unsigned*)(lds_act + G::kAPlane + rl * G::kA8Ld + lo8_pos(col)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+      }
     }
   }
 }
@@ -575,52 +649,49 @@ __device__ __forceinline__ void rows_to_planes(char* lds_act, float4 (&v)[N], in
 struct NoPrefetch {
   __device__ __forceinline__ void operator()() const {}
 };
-// `after_loads()` runs once, right after the row loads have been issued and before their first use: the place
-// to start the weight streams.  (Loads return in order: a weight prefetch issued BEFORE the rows makes the
+// x fp32 [M][D] -> (optional LayerNorm) -> planes.  Each wave handles RPW rows; a row is Q coalesced 1 KiB float4 loads.
+// `after_loads()` runs once, right after the first batch of row loads has been issued and before their first use: the
+// place to start the weight streams.  (Loads return in order: a weight prefetch issued BEFORE the rows makes the
 // LayerNorm wait behind ~100 KiB of weight traffic.)
-template <int NP, bool DO_LN, int RPW = 16, typename After = NoPrefetch>
+template <int D, int NP, bool DO_LN, typename After = NoPrefetch>
 __device__ __forceinline__ void rows_f32_to_planes(char* lds_act, const float* __restrict__ x, int row0, int M,
                                                    const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, After after_loads = After()) {
+  using G = Geo<D>;
+  constexpr int RPW = G::kRPW;
   const int lane = lane_id(), w = wave_id();
-  float4 g = make_float4(1.f, 1.f, 1.f, 1.f), bt = make_float4(0.f, 0.f, 0.f, 0.f);
+  RowV<G::kQ> g, bt;
   if (DO_LN) {
-    g = ((const float4*)gamma)[lane];
-    bt = ((const float4*)beta)[lane];
+    g = load_row<D>(gamma, lane);
+    bt = load_row<D>(beta, lane);
   }
-  constexpr int NB = (RPW < 8) ? RPW : 8;  // rows per batch
+  RowV<G::kQ> v[RPW];
 #pragma unroll
-  for (int b0 = 0; b0 < RPW; b0 += NB) {
-    float4 v[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int row = row0 + w * RPW + b0 + i;
-      v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) v[i] = ((const float4*)(x + (size_t)row * kD))[lane];
-    }
-    if (b0 == 0) {
-      __builtin_amdgcn_sched_barrier(0);
-      after_loads();
-    }
-    if (DO_LN) layer_norm_rows<NB>(v, g, bt);
-    rows_to_planes<NP, NB>(lds_act, v, w * RPW + b0, row0, M, DO_LN);
+  for (int i = 0; i < RPW; ++i) {
+    const int row = row0 + w * RPW + i;
+    v[i] = zero_row<G::kQ>();
+    if (row < M) v[i] = load_row<D>(x + (size_t)row * D, lane);
   }
+  __builtin_amdgcn_sched_barrier(0);
+  after_loads();
+  if (DO_LN) layer_norm_rows<D, RPW>(v, g, bt);
+  rows_to_planes<D, NP, RPW>(lds_act, v, w * RPW, row0, M, DO_LN);
 }
 
-// acc[MT=2][NT] (normal orientation, wave owns columns col0 + nt*32 ..) + bias -> fp32 tile in LDS.
-template <int NT>
-__device__ __forceinline__ void acc_to_etile(char* lds_e, const f32x16 (&acc)[2][NT], int col0,
+// acc[MT][NT] (normal orientation, wave owns columns col0 + nt*32 ..) + bias -> fp32 tile in LDS (row stride e_ld).
+template <int MT, int NT>
+__device__ __forceinline__ void acc_to_etile(char* lds_e, int e_ld, const f32x16 (&acc)[MT][NT], int col0,
                                              const float* __restrict__ bias, int lane = lane_id()) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int col = col0 + nt * 32 + (lane & 31);
     const float b = bias ? bias[col] : 0.0f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int r = mt * 32 + acc_row(i, lane);
-        *(float*)(lds_e + r * kELd + col * 4) = acc[mt][nt][i] + b;
+        *(float*)(lds_e + r * e_ld + col * 4) = acc[mt][nt][i] + b;
       }
   }
 }

@@ -9,8 +9,8 @@ namespace eec {
 hipError_t ensure_max_lds(const void* kernel, int bytes);
 
 struct FfnArgs {
-  float* x;  // [M][256] fp32, updated in place
-  int M, F;
+  float* x;  // [M][D] fp32, updated in place
+  int M, F, D;
   const float *ln_g, *ln_b;
   const uint4* w1p;  // packed log2(e) * W1 [F][256]
   const float* b1;   // log2(e) * b1
@@ -28,8 +28,8 @@ struct DwArgs;
 struct ProjResArgs;
 
 struct QkvArgs {
-  const float* x;  // [M][256]
-  int M, B, Tq, Tp, H;  // Tq = T' (frames per utterance), Tp = padded to 32
+  const float* x;  // [M][D]
+  int M, B, Tq, Tp, H, D;  // Tq = T' (frames per utterance), Tp = padded to 32
   const float *ln_g, *ln_b;
   const uint4* wp;  // packed in_proj_weight [768][256]
   const float* bias;  // [768]
@@ -40,14 +40,14 @@ hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
 struct ProjResArgs {  // x += planes . W^T + bias   (attention out-proj; also the GEMM half of dw_pw2 / proj_glu)
   float* x;
-  int M;
+  int M, D;
   const half_t *a_hi, *a_lo;  // [M][256]
   const uint4* wp;            // packed [256][256]
   const float* bias;
 };
 hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st);
 
-struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,256), gate cols [256,512)
+struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,D), gate cols [D,2D)
   const float* x;
   int M;
   const float *ln_g, *ln_b;
@@ -60,7 +60,7 @@ hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipSt
 
 struct HeadArgs {  // out = log_softmax(x . W^T + b)
   const float* x;
-  int M, V;
+  int M, V, D;
   const uint4* wp;  // packed [V][256]
   const float* bias;
   float* out;  // [M][V]
@@ -75,7 +75,7 @@ struct HeadBatchArgs {
   const uint4* wp[kMaxHeadExits];
   const float* bias[kMaxHeadExits];
   float* out;  // [E][M][V]
-  int M, V, E;
+  int M, V, E, D;
 };
 hipError_t launch_head_batch(const HeadBatchArgs& a, int np, hipStream_t st);
 
@@ -89,10 +89,10 @@ struct AttnArgs {
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st);
 
 struct DwArgs {
-  const half_t* g;  // [B*Tq][256]
+  const half_t* g;  // [B*Tq][D]
   int B, Tq;
-  const float* wfold;  // [31][256] taps (BN folded, zero padded to 31, centred)
-  const float* bfold;  // [256]
+  const float* wfold;  // [31][D] taps (BN folded, zero padded to 31, centred)
+  const float* bfold;  // [D]
   half_t *o_hi, *o_lo;  // unused by the fused kernel (kept for layout compatibility of the argument block)
 };
 // fused depthwise conv + BN + SiLU -> pointwise-2 + residual (o_hi/o_lo of DwArgs are unused)
@@ -111,8 +111,8 @@ struct FfnStage {
   float* tap;                  // optional [M][256]: the stage's output rows are stored here too (exit taps)
 };
 struct ChainArgs {
-  float* x;  // [M][256] residual stream, updated in place
-  int M, F, nstage;
+  float* x;  // [M][D] residual stream, updated in place
+  int M, F, nstage, D;
   FfnStage st[2];
   QkvArgs qkv;      // tail (x / M of this block are ignored)
   DwArgs dw;        // front
@@ -122,7 +122,8 @@ hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tai
 
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]
-  int B, n_mels, T, T1, Tq;
+  int B, n_mels, T, T1, Tq, D;
+  int* mel_e;        // [B]: per-utterance power-of-two exponent of the scaled fp16 domain (written by the stem launch)
   const uint4* w1p;       // packed conv1 weight as [256][n_mels*3] (its own [ci][j] flattening)
   const float* b1;
   const uint4* w2p;       // packed conv2 weight as [256][3*256], k ordered (j, ci)
@@ -139,7 +140,7 @@ hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float sca
 hipError_t launch_pack_frags_f8(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // NP == 8 stream (K % 64 == 0)
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,
-                          const float* bn_rm, const float* bn_rv, int ksize, float* wfold, float* bfold,
+                          const float* bn_rm, const float* bn_rv, int ksize, int D, float* wfold, float* bfold,
                           hipStream_t st);
 // conv weight [co][ci][3] -> fragments of the [co][3*ci_total] matrix with k ordered (j, ci)
 hipError_t launch_pack_conv_jci(const float* w, int cout, int cin, uint4* out, hipStream_t st);

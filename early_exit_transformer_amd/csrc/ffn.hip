@@ -34,8 +34,15 @@ namespace eec {
 constexpr int kFfnThreads = 512;
 constexpr int kFC = 128;                          // hidden units per chunk (4 waves x 32)
 constexpr int kHLd = (kFC + 8) * 2;               // 272
-constexpr int kHPlane = kTileRows * kHLd;         // 17408
-constexpr int kFfnLds = 2 * kAPlane + 4 * kHPlane;  // A hi/lo + per-group H hi/lo = 137216
+template <int D>
+struct FfnGeo {
+  using G = Geo<D>;
+  static constexpr int kHPlane = G::kRows * kHLd;                 // 17408 / 8704
+  static constexpr int kNT2 = D / 128;                            // output column tiles per consumer wave: 2 / 4
+  // A hi/lo planes + two H buffers of two planes each; the fp32 exchange tile of the row passes aliases the H buffers
+  // (D = 256: it fits inside them; D = 512: it is the larger of the two)
+  static constexpr int kLds = 2 * G::kAPlane + (4 * kHPlane > G::kETile ? 4 * kHPlane : G::kETile);  // 137216 / 132608
+};
 // k-steps of W1 / W2 fragments a producer / consumer wave keeps in flight.  The shared weight stream
 // out of L2 is latency x concurrency bound (tools/l2bw.hip: 64 KiB in flight per CU -> 18 TB/s,
 // 128 KiB -> 28 TB/s), so the rings are as deep as the register budget allows.
@@ -45,13 +52,14 @@ constexpr int kFfnLds = 2 * kAPlane + 4 * kHPlane;  // A hi/lo + per-group H hi/
 #define EEC_PF1_NP1 12
 #define EEC_PF2_NP1 8
 #endif
-template <int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = EEC_PF2_NP3; };
-template <> struct FfnPf<1> { static constexpr int P1 = EEC_PF1_NP1, P2 = EEC_PF2_NP1; };
+// (D = 512: a consumer's ring holds 4 column tiles per k-step instead of 2, so it is half as deep)
+template <int D, int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = D == 512 ? EEC_PF2_NP3 / 2 : EEC_PF2_NP3; };
+template <int D> struct FfnPf<D, 1> { static constexpr int P1 = EEC_PF1_NP1, P2 = D == 512 ? EEC_PF2_NP1 / 2 : EEC_PF2_NP1; };
 #ifndef EEC_PF1_NP8
 #define EEC_PF1_NP8 6
 #define EEC_PF2_NP8 3
 #endif
-template <> struct FfnPf<8> { static constexpr int P1 = EEC_PF1_NP8, P2 = EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+template <int D> struct FfnPf<D, 8> { static constexpr int P1 = EEC_PF1_NP8, P2 = D == 512 ? 2 : EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
 #ifndef EEC_DROP1
 #define EEC_DROP1 0  // diagnostic: correction terms of GEMM1 / GEMM2 to skip (see gemm_ring_f8)
 #define EEC_DROP2 0
@@ -69,7 +77,7 @@ constexpr int kNW1 = EEC_NW1;
 constexpr int kNW2 = EEC_NW2;  // lo8 group buffers of the consumers' GEMM2 (2 = whole stage resident)  // lo8 group buffers of the producers' GEMM1 (4 = whole stage resident)
 constexpr int kH8Ld = kFC + 16;  // 144: H lo8 byte plane row stride (NP == 8)
 
-#ifdef EEC_TIMELINE
+#if defined(EEC_TIMELINE) && (!defined(EEC_FFN_D) || EEC_FFN_D == 256)
 // Diagnostic build only: s_memtime stamps of wave 0 (consumer slot of the buffer) and wave 4 of the first
 // 8 workgroups, written to a buffer nothing else reads.  Layout: [block][role][stamp], 128 stamps.
 __device__ unsigned long long* g_timeline = nullptr;
@@ -113,10 +121,6 @@ __device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, 
   const size_t ln = ((blockIdx.x >> 3) & 31) * per_wg + wl * per_wave + k;
   return (k < per_wave && ln < n_lines) ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
 }
-template <int I>
-struct IntTag {
-  static constexpr int value = I;
-};
 // f(IntTag<0>{}), ..., f(IntTag<N-1>{}) for N <= 2: a stage loop whose index is a compile-time constant
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -137,34 +141,39 @@ struct WPtrs {
 // included) is scaled and - HAS_RES - added to the residual rows `xr` (wave w owns local rows 8w .. 8w+7, one float4 per lane), the
 // optional final LayerNorm is applied, the rows are stored to x (and to `tap`), and - NPN != 0 - the rows are
 // LayerNormed with (nln_g, nln_b) and written as the NEXT stage's activation planes (NPN format) at `smem`.
-template <int NPN, bool HAS_RES>
-__device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, float* __restrict__ x, float4 (&xr)[8],
+template <int D, int NPN, bool HAS_RES>
+__device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, float* __restrict__ x, RowV<Geo<D>::kQ> (&xr)[Geo<D>::kRPW],
                                               int row0, int M, float scale, const float* __restrict__ fin_g,
                                               const float* __restrict__ fin_b, float* __restrict__ tap,
                                               const float* __restrict__ nln_g, const float* __restrict__ nln_b,
                                               int lane = lane_id(), int w = wave_id()) {
-  float4 v[8];
+  using G = Geo<D>;
+  constexpr int RPW = G::kRPW, Q = G::kQ;
+  RowV<Q> v[RPW];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float4 e = *(const float4*)(lds_e + (w * 8 + i) * kELd + lane * 16);
-    v[i] = HAS_RES ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);  // !HAS_RES: the residual went in as the accumulator init
-    v[i].x += scale * e.x;
-    v[i].y += scale * e.y;
-    v[i].z += scale * e.z;
-    v[i].w += scale * e.w;
+  for (int i = 0; i < RPW; ++i) {
+    v[i] = HAS_RES ? xr[i] : zero_row<Q>();  // !HAS_RES: the residual went in as the accumulator init
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float4 e = *(const float4*)(lds_e + (w * RPW + i) * G::kELd + (q * 256 + lane * 4) * 4);
+      v[i].p[q].x += scale * e.x;
+      v[i].p[q].y += scale * e.y;
+      v[i].p[q].z += scale * e.z;
+      v[i].p[q].w += scale * e.w;
+    }
   }
-  if (fin_g) layer_norm_rows<8>(v, ((const float4*)fin_g)[lane], ((const float4*)fin_b)[lane]);
+  if (fin_g) layer_norm_rows<D, RPW>(v, load_row<D>(fin_g, lane), load_row<D>(fin_b, lane));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int row = row0 + w * 8 + i;
+  for (int i = 0; i < RPW; ++i) {
+    const int row = row0 + w * RPW + i;
     if (row < M) {
-      ((float4*)(x + (size_t)row * kD))[lane] = v[i];
-      if (tap) ((float4*)(tap + (size_t)row * kD))[lane] = v[i];
+      store_row<D>(x + (size_t)row * D, v[i], lane);
+      if (tap) store_row<D>(tap + (size_t)row * D, v[i], lane);
     }
   }
   if constexpr (NPN != 0) {
-    layer_norm_rows<8>(v, ((const float4*)nln_g)[lane], ((const float4*)nln_b)[lane]);
-    rows_to_planes<NPN, 8>(smem, v, w * 8, row0, M, true, lane);
+    layer_norm_rows<D, RPW>(v, load_row<D>(nln_g, lane), load_row<D>(nln_b, lane));
+    rows_to_planes<D, NPN, RPW>(smem, v, w * RPW, row0, M, true, lane);
   }
 }
 
@@ -175,10 +184,15 @@ __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, flo
 //   FNP  0: stage 0 reads x;  else: the depthwise + pointwise-2 front (format FNP) produces x first
 //   QNP  0: none;  else: the attention in_proj of the NEXT half-layer (format QNP) runs on the final rows
 //   NS   number of FFN stages (1 or 2)
-template <int NP, int ACT, int FNP, int QNP, int NS>
+template <int D, int NP, int ACT, int FNP, int QNP, int NS>
 __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) {
+  using G = Geo<D>;
+  using FG = FfnGeo<D>;
+  constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS, RPW = G::kRPW, NT2 = FG::kNT2;
+  constexpr int kALd = G::kALd, kAPlane = G::kAPlane, kA8Ld = G::kA8Ld, kHPlane = FG::kHPlane;
+  constexpr size_t nts = (size_t)KS * 128;  // uint4 between adjacent n-tiles of a K = D matrix
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int kPF1 = FfnPf<NP>::P1, kPF2 = FfnPf<NP>::P2;
+  constexpr int kPF1 = FfnPf<D, NP>::P1, kPF2 = FfnPf<D, NP>::P2;
   const int lane = lane_id(), w = wave_id();
   const int hh = lane >> 5, wl = w & 3;
   const int w_s = wave_id_sgpr();
@@ -186,10 +200,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // priority, then age, and the producers are the critical path of the chunk pipeline (measured -2.3 % forward against
   // the opposite assignment; raising their priority with s_setprio instead makes it slower)
   const bool is_producer = w < 4;
-  const int row0 = blockIdx.x * kTileRows;
+  const int row0 = blockIdx.x * G::kRows;
   const int M = a.M, F = a.F;
   float* __restrict__ x = a.x;
-  char* lds_h = smem + 2 * kAPlane;  // H[buf][plane][64][136]
+  char* lds_h = smem + 2 * kAPlane;  // H[buf][plane][rows][136]
   char* lds_e = lds_h;               // fp32 exchange tile: aliases the H buffers (dead outside the chunk loops), not the planes
   const char* a_lane = smem + (lane & 31) * kALd + hh * 16;
 
@@ -231,28 +245,28 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   auto run = [&](auto prod_tag) {
   constexpr bool producer = decltype(prod_tag)::value;
   WRing<RNP, kPF1, 1> r1;
-  WRing<RNP, kPF2, 2> r2;
-  WGroupF8<1> wg1[kNW1];  // NP == 8: lo8 + scales of GEMM1 (K = 256 = 4 groups), rolling through kNW1 buffers
-  WGroupF8<2> wg2[kNW2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, 2 n-tiles)
+  WRing<RNP, kPF2, NT2> r2;
+  WGroupF8<1> wg1[kNW1];    // NP == 8: lo8 + scales of GEMM1 (K = D = D/64 groups), rolling through kNW1 buffers
+  WGroupF8<NT2> wg2[kNW2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, NT2 n-tiles)
   const size_t w2f8_nt = (size_t)(F / 64) * kF8Rec;
-  auto w1f8_lane = [&](const WPtrs& W, int ft) { return W.w1f8 + (size_t)ft * 4 * kF8Rec + lane; };
-  auto w2f8_lane = [&](const WPtrs& W, int c) { return W.w2f8 + ((size_t)(2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
+  auto w1f8_lane = [&](const WPtrs& W, int ft) { return W.w1f8 + (size_t)ft * (D / 64) * kF8Rec + lane; };
+  auto w2f8_lane = [&](const WPtrs& W, int c) { return W.w2f8 + ((size_t)(NT2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
   auto fill1 = [&](const WPtrs& W, int ft) {  // start the W1 stream of hidden tile ft
     if constexpr (NP == 8) {
       ring_fill_f8<kPF1, 1>(r1, w1f8_lane(W, ft), 0);
 #pragma unroll
       for (int g = 0; g < kNW1; ++g) f8_group_load<1>(wg1[g], w1f8_lane(W, ft) + (size_t)g * kF8Rec, 0);
     } else {
-      ring_fill<RNP, kPF1, 1>(r1, W.w1p + (size_t)ft * (kD / 16) * 128 + lane, 0, kD / 16);
+      ring_fill<RNP, kPF1, 1>(r1, W.w1p + (size_t)ft * nts + lane, 0, KS);
     }
   };
   auto fill2 = [&](const WPtrs& W, int c) {  // start the W2 stream of chunk c
     if constexpr (NP == 8) {
-      ring_fill_f8<kPF2, 2>(r2, w2f8_lane(W, c), w2f8_nt);
+      ring_fill_f8<kPF2, NT2>(r2, w2f8_lane(W, c), w2f8_nt);
 #pragma unroll
-      for (int g = 0; g < kNW2; ++g) f8_group_load<2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
+      for (int g = 0; g < kNW2; ++g) f8_group_load<NT2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
     } else {
-      ring_fill<RNP, kPF2, 2>(r2, W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
+      ring_fill<RNP, kPF2, NT2>(r2, W.w2p + ((size_t)(NT2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
                              min(kFC / 16, ks2_total - c * (kFC / 16)));
     }
   };
@@ -274,12 +288,12 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   unsigned sink_front = 0;
   // ---- planes of stage 0 ----
   if constexpr (FNP != 0) {
-    WRing<FNP, kDPF, 1> rp;
-    ring_fill<FNP, kDPF, 1>(rp, a.pw2.wp + (size_t)w * (kD / 16) * 128 + lane, 0, kD / 16);
+    WRing<FNP, kDPF, NW> rp;
+    ring_fill<FNP, kDPF, NW>(rp, wfrag_lane<KS>(a.pw2.wp, NW * w), nts, KS);
 #if EEC_WARM_SLOTS > 0
     {  // stage 0's weights are cold in this XCD's L2: fetch this workgroup's share while the conv front runs
       const WPtrs W0 = wptrs(0);
-      const size_t wbytes = NP == 8 ? (size_t)(F / 32) * 4 * kF8Rec * 16 : (size_t)F * kD * 2 * (NP == 3 ? 2 : 1);
+      const size_t wbytes = NP == 8 ? (size_t)(F / 32) * (D / 64) * kF8Rec * 16 : (size_t)F * D * 2 * (NP == 3 ? 2 : 1);
       unsigned t = 0;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -289,34 +303,34 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
       sink_front = t;
     }
 #endif
-    dw_front<FNP>(smem, a.dw, M, row0);
-    float4 xr[8];  // residual rows: requested now, consumed after the pointwise-2 GEMM
+    dw_front<D, FNP>(smem, a.dw, M, row0);
+    RowV<G::kQ> xr[RPW];  // residual rows: requested now, consumed after the pointwise-2 GEMM
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = row0 + w * 8 + i;
-      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane];
+    for (int i = 0; i < RPW; ++i) {
+      const int row = row0 + w * RPW + i;
+      xr[i] = zero_row<G::kQ>();
+      if (row < M) xr[i] = load_row<D>(x + (size_t)row * D, lane);
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // conv planes complete; the staged GLU rows / taps are dead
-    f32x16 accp[2][1];
-    pw2_gemm<FNP>(accp, smem, a.pw2, rp);
+    f32x16 accp[MT][NW];
+    pw2_gemm<D, FNP>(accp, smem, a.pw2, rp);
     start_streams(wptrs(0));
-    acc_swapped_to_etile(lds_e, accp);
+    acc_swapped_to_etile<MT, NW>(lds_e, G::kELd, accp, 32 * NW * w);
     __syncthreads();  // tile complete; every wave is done reading the conv planes
-    chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
+    chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
   } else {
     const WPtrs W0 = wptrs(0);
-    rows_f32_to_planes<NP, true, 8>(smem, x, row0, M, a.st[0].ln_g, a.st[0].ln_b, [&]() { start_streams(W0); });
+    rows_f32_to_planes<D, NP, true>(smem, x, row0, M, a.st[0].ln_g, a.st[0].ln_b, [&]() { start_streams(W0); });
   }
   TL_STAMP();  // 1: prologue done
   __syncthreads();
   TL_STAMP();  // 2: after prologue barrier
 
-  [[maybe_unused]] WRing<(QNP ? QNP : 1), kLPF> rq;  // tail: first k-steps of this wave's Q weight tile
+  [[maybe_unused]] WRing<(QNP ? QNP : 1), kLPF, NW> rq;  // tail: first k-steps of this wave's Q weight tiles
   unsigned sink = 0;  // keeps the L2 warm-up loads alive
   const int nslots = nchunk + 2;
-  f32x16 acc2c[2][2];  // consumers' [64 x 64] output accumulators (unused by producers)
+  f32x16 acc2c[MT][NT2];  // consumers' [rows x D/4] output accumulators (unused by producers)
   static_for<NS>([&](auto si_tag) {
     constexpr int si = decltype(si_tag)::value;  // NS is a template parameter and the loop is unrolled: as a runtime loop it makes
                                      // every ring and accumulator loop-carried (~250 spilled VGPRs in the hot loops)
@@ -328,7 +342,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
     if constexpr (producer) {
       // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
-      auto silu_pair = [&](const f32x16 (&acc)[2][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
+      auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
         const int mt = step >> 3, q = step & 7;
         const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
         constexpr int SNP = NP == 1 ? 1 : 3;
@@ -349,12 +363,12 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           }
         }
       };
-      auto init_bias = [&](f32x16 (&acc)[2][1], int ft) {
+      auto init_bias = [&](f32x16 (&acc)[MT][1], int ft) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt) {
+          for (int mt = 0; mt < MT; ++mt) {
             acc[mt][0][4 * g + 0] = bb.x;
             acc[mt][0][4 * g + 1] = bb.y;
             acc[mt][0][4 * g + 2] = bb.z;
@@ -363,7 +377,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
         }
       };
       // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
-      auto slot = [&](int s, f32x16 (&cur)[2][1], f32x16 (&prev)[2][1]) {
+      // the SiLU side work of one chunk = 8 MT value pairs, spread over the KS k-steps of the next chunk's GEMM1
+      constexpr int kSideEvery = KS / (8 * MT);  // 1 (D = 256) / 4 (D = 512)
+      auto slot = [&](int s, f32x16 (&cur)[MT][1], f32x16 (&prev)[MT][1]) {
         const int ft = (s < nchunk ? phys(s) : s) * 4 + wl;  // s >= nchunk: no GEMM1 (ft is out of range)
         const bool do_gemm = s < nchunk && ft < nft;
         const bool do_silu = s >= 1 && s - 1 < nchunk && phys(s - 1) * 4 + wl < nft;
@@ -371,37 +387,39 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
         h2 khi, klo;
         if (do_gemm) {
           init_bias(cur, ft);
-          const uint4* w1_lane = W.w1p + (size_t)ft * (kD / 16) * 128 + lane;
+          const uint4* w1_lane = W.w1p + (size_t)ft * nts + lane;
           const char* a8_lane = smem + kAPlane + (lane & 31) * kA8Ld + hh * 32;
           if (do_silu) {
-            auto side = [&](int st) { silu_pair(prev, hb_prev, st, khi, klo); };
+            auto side = [&](int st) {
+              if (st % kSideEvery == 0) silu_pair(prev, hb_prev, st / kSideEvery, khi, klo);
+            };
             if constexpr (NP == 8)
-              gemm_ring_f8<4, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
+              gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
-              gemm_ring<RNP, kD / 16, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7)>(cur, a_lane, kALd, kAPlane, w1_lane,
-                                                                                       0, r1, side);
+              gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7), MT>(cur, a_lane, kALd, kAPlane, w1_lane,
+                                                                                      0, r1, side);
           } else {
             if constexpr (NP == 8)
-              gemm_ring_f8<4, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
+              gemm_ring_f8<D / 64, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1, MT>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
             else
-              gemm_ring<RNP, kD / 16, 1, true, kPF1>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
+              gemm_ring<RNP, KS, 1, true, kPF1, NoSide, 0, MT>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
           }
           if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(W, phys(s + 1) * 4 + wl);  // next chunk's W1 stream
         } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
 #pragma unroll
-          for (int st = 0; st < 16; ++st) silu_pair(prev, hb_prev, st, khi, klo);
+          for (int st = 0; st < 8 * MT; ++st) silu_pair(prev, hb_prev, st, khi, klo);
         }
         TL_STAMP();  // producer: slot work done
         __syncthreads();
         TL_STAMP();  // producer: barrier passed
       };
-      f32x16 accA[2][1], accB[2][1];
+      f32x16 accA[MT][1], accB[MT][1];
       for (int s = 0; s < nslots; s += 2) {
         slot(s, accA, accB);
         if (s + 1 < nslots) slot(s + 1, accB, accA);
       }
     } else {
-      f32x16 (&acc2)[2][2] = acc2c;
+      f32x16 (&acc2)[MT][NT2] = acc2c;
       zero_acc(acc2);
 #if EEC_WARM_SLOTS > 0
       unsigned warm[4] = {0u, 0u, 0u, 0u};
@@ -415,14 +433,14 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           const int lane_t = fresh_lane();
           if constexpr (si + 1 < NS) {
             const WPtrs Wn = wptrs(si + 1);
-            const size_t wbytes = NP == 8 ? (size_t)(F / 32) * 4 * kF8Rec * 16 : (size_t)F * kD * 2 * (NP == 3 ? 2 : 1);
+            const size_t wbytes = NP == 8 ? (size_t)(F / 32) * (D / 64) * kF8Rec * 16 : (size_t)F * D * 2 * (NP == 3 ? 2 : 1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, w_s & 3, j, lane_t);
               warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, w_s & 3, j, lane_t);
             }
           } else if constexpr (QNP != 0) {
-            warm[0] = touch_share(a.qkv.wp, (size_t)3 * kD * kD * 2 * (QNP == 3 ? 2 : 1), w_s & 3, 0, lane_t);
+            warm[0] = touch_share(a.qkv.wp, (size_t)3 * D * D * 2 * (QNP == 3 ? 2 : 1), w_s & 3, 0, lane_t);
           }
         }
 #endif
@@ -430,14 +448,14 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           const int cl = s - 2, c = phys(cl);  // logical slot chunk (picks the H buffer) / physical hidden chunk
           const char* h_lane = lds_h + (cl & 1) * 2 * kHPlane + (lane & 31) * kHLd + hh * 16;
           const int ks2 = min(kFC / 16, ks2_total - c * (kFC / 16));
-          const uint4* w2_lane = W.w2p + ((size_t)(2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
+          const uint4* w2_lane = W.w2p + ((size_t)(NT2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
           if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
             const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
-            gemm_ring_f8<2, 2, false, kPF2, NoSide, 0, kNW2, EEC_DROP2>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
+            gemm_ring_f8<2, NT2, false, kPF2, NoSide, 0, kNW2, EEC_DROP2, MT>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
           } else if (ks2 == kFC / 16) {
-            gemm_ring<RNP, kFC / 16, 2, false, kPF2>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+            gemm_ring<RNP, kFC / 16, NT2, false, kPF2, NoSide, 0, MT>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
           } else {
-            gemm_plain<RNP, 2, false>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+            gemm_plain<RNP, NT2, false, MT>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
           }
           if (cl + 1 < nchunk) fill2(W, phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
         }
@@ -453,19 +471,19 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // residual rows of this wave: issued now, consumed after the tile exchange below (for a second stage
     // they are the rows this very thread stored in the previous row pass)
     const int lane_e = fresh_lane(), w_e = w_s;  // see fresh_lane(): nothing index-like stays live across the chunk loops
-    float4 xr[8];
+    RowV<G::kQ> xr[RPW];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int row = row0 + w_e * 8 + i;
-      xr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < M) xr[i] = ((const float4*)(x + (size_t)row * kD))[lane_e];
+    for (int i = 0; i < RPW; ++i) {
+      const int row = row0 + w_e * RPW + i;
+      xr[i] = zero_row<G::kQ>();
+      if (row < M) xr[i] = load_row<D>(x + (size_t)row * D, lane_e);
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr bool more = si + 1 < NS;
     // the consumers hold the [64, 256] result: stage it through the fp32 tile (the last barrier of the
     // loops guarantees that nobody still reads the H buffers it aliases)
     TL_STAMP();  // residual loads issued
-    if constexpr (!producer) acc_to_etile<2>(lds_e, acc2c, (w_e & 3) * 64, EEC_STAGE_FIELD(si, b2), lane_e);
+    if constexpr (!producer) acc_to_etile<MT, NT2>(lds_e, G::kELd, acc2c, (w_e & 3) * 32 * NT2, EEC_STAGE_FIELD(si, b2), lane_e);
     TL_STAMP();  // exchange tile written
     // the next phase's weight streams start only now, when the accumulators are dead (issued earlier, their
     // registers push the allocator into spilling, and scratch reloads queue behind these cold loads); the
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     if constexpr (more) {
       start_streams(wptrs(1));
     } else if constexpr (QNP != 0) {
-      ring_fill<QNP, kLPF, 1>(rq, wfrag_lane(a.qkv.wp, w), 0, kD / 16);
+      ring_fill<QNP, kLPF, NW>(rq, wfrag_lane<KS>(a.qkv.wp, NW * w), nts, KS);
     }
     __syncthreads();
     TL_STAMP();  // barrier
@@ -481,17 +499,17 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
     float* tap = EEC_STAGE_FIELD(si, tap);
     if constexpr (more) {  // only stage 0 can have a successor
-      chain_rowpass<NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b, lane_e, w_e);
+      chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b, lane_e, w_e);
     } else if constexpr (QNP != 0) {
-      chain_rowpass<QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b, lane_e, w_e);
+      chain_rowpass<D, QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b, lane_e, w_e);
     } else {
-      chain_rowpass<0, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, nullptr, nullptr, lane_e, w_e);
+      chain_rowpass<D, 0, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, nullptr, nullptr, lane_e, w_e);
     }
     TL_STAMP();  // row pass done
     if (more || QNP != 0) __syncthreads();  // next planes complete; the exchange tile is free again
     TL_STAMP();  // stage epilogue + row pass done
   });
-  if constexpr (QNP != 0) qkv_body<QNP>(smem, a.qkv, row0, rq);
+  if constexpr (QNP != 0) qkv_body<D, QNP>(smem, a.qkv, row0, rq);
   if ((sink ^ sink_front) == 0x9e3779b9u && M == -7) x[0] = 0.f;  // never true: the warm-up loads must not be optimised away
   TL_STAMP();  // last: epilogue done
   };
@@ -501,7 +519,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     run(BoolTag<false>{});
 }
 
-#ifdef EEC_TIMELINE
+#if defined(EEC_TIMELINE) && (!defined(EEC_FFN_D) || EEC_FFN_D == 256)
 extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
   static unsigned long long* dev = nullptr;
   if (!dev) {
@@ -515,32 +533,42 @@ extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
 }
 #endif
 
-template <int NP, int ACT, int FNP, int QNP, int NS>
+template <int D, int NP, int ACT, int FNP, int QNP, int NS>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
-  auto k = ffn_chain_kernel<NP, ACT, FNP, QNP, NS>;
-  constexpr int lds = FNP != 0 ? (kDwLds > kFfnLds ? kDwLds : kFfnLds) : kFfnLds;
+  auto k = ffn_chain_kernel<D, NP, ACT, FNP, QNP, NS>;
+  constexpr int lds = FNP != 0 ? (DwGeo<D>::kLds > FfnGeo<D>::kLds ? DwGeo<D>::kLds : FfnGeo<D>::kLds) : FfnGeo<D>::kLds;
   if (hipError_t e = ensure_max_lds((const void*)k, lds); e != hipSuccess) return e;
-  const int grid = (a.M + kTileRows - 1) / kTileRows;
+  const int grid = (a.M + Geo<D>::kRows - 1) / Geo<D>::kRows;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kFfnThreads), lds, st, a);
   return hipGetLastError();
 }
 
+// This file is compiled once per d_model (-DEEC_FFN_D=256 / 512: two objects, so the two sets of chain-kernel variants
+// build in parallel); each object defines launch_ffn_chain_d<EEC_FFN_D>, the D = 256 object also the dispatchers.
+#ifndef EEC_FFN_D
+#define EEC_FFN_D 256
+#endif
+template <int D>
+hipError_t launch_ffn_chain_d(const ChainArgs& a_in, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st);
+
 // np: FFN format (1, 3, 8); np_o: format of the optional front / tail (1 or 3)
-hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st) {
+template <>
+hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st) {
+  constexpr int D = EEC_FFN_D;
   ChainArgs a = a_in;
   if (a.nstage < 1 || a.nstage > 2) return hipErrorInvalidValue;
   for (int i = 0; i < a.nstage; ++i)
     if (np == 8 && (a.F % kFC != 0 || !a.st[i].w1f8 || !a.st[i].w2f8)) np = 3;  // the f8 stream needs whole 128-wide chunks
   if (relu) {
     if (front || tail || a.nstage != 1) return hipErrorInvalidValue;
-    if (np == 8) return launch_chain_t<8, 1, 0, 0, 1>(a, st);
-    if (np == 3) return launch_chain_t<3, 1, 0, 0, 1>(a, st);
-    return launch_chain_t<1, 1, 0, 0, 1>(a, st);
+    if (np == 8) return launch_chain_t<D, 8, 1, 0, 0, 1>(a, st);
+    if (np == 3) return launch_chain_t<D, 3, 1, 0, 0, 1>(a, st);
+    return launch_chain_t<D, 1, 1, 0, 0, 1>(a, st);
   }
   const int f = front ? np_front : 0, q = tail ? np_tail : 0;
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
   if (np == NP_ && f == F_ && q == Q_)                                                                   \
-    return a.nstage == 2 ? launch_chain_t<NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<NP_, 0, F_, Q_, 1>(a, st);
+    return a.nstage == 2 ? launch_chain_t<D, NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<D, NP_, 0, F_, Q_, 1>(a, st);
   EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 3, 3)
   EEC_CHAIN_CASE(3, 0, 0) EEC_CHAIN_CASE(3, 3, 0) EEC_CHAIN_CASE(3, 0, 3) EEC_CHAIN_CASE(3, 3, 3)
   EEC_CHAIN_CASE(1, 0, 0) EEC_CHAIN_CASE(1, 3, 0) EEC_CHAIN_CASE(1, 0, 3) EEC_CHAIN_CASE(1, 3, 3)
@@ -552,12 +580,23 @@ hipError_t launch_ffn_chain(const ChainArgs& a_in, int np, int np_front, int np_
   return hipErrorInvalidValue;
 }
 
+#if EEC_FFN_D == 256
+template <>
+hipError_t launch_ffn_chain_d<512>(const ChainArgs& a_in, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st);  // ffn512.o
+
+hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st) {
+  if (a.D == 512) return launch_ffn_chain_d<512>(a, np, np_front, np_tail, front, tail, relu, st);
+  if (a.D == 256) return launch_ffn_chain_d<256>(a, np, np_front, np_tail, front, tail, relu, st);
+  return hipErrorInvalidValue;
+}
+
 // single stand-alone stage (the unfused plan and the legacy encoder)
 hipError_t launch_ffn(const FfnArgs& f, int np, hipStream_t st) {
   ChainArgs a{};
-  a.x = f.x, a.M = f.M, a.F = f.F, a.nstage = 1;
+  a.x = f.x, a.M = f.M, a.F = f.F, a.D = f.D, a.nstage = 1;
   a.st[0] = FfnStage{f.ln_g, f.ln_b, f.w1p, f.b1, f.w2p, f.b2, f.fin_g, f.fin_b, f.w1f8, f.w2f8, f.res_scale, nullptr};
   return launch_ffn_chain(a, np, 3, 3, false, false, f.relu, st);
 }
+#endif
 
 }  // namespace eec

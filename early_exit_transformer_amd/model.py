@@ -458,6 +458,19 @@ class Early_zipformer(_HipEncoderMixin, nn.Module):
         return out
 
 
+def encoder_lengths(lengths: Tensor, t_out: int) -> Tensor:
+    """``clamp(lengths / 4, max=T').to(int)`` (early_exit.py:623) on the device: int64 [B] -> int32 [B]."""
+    if not lengths.is_cuda:
+        raise RuntimeError("encoder_lengths runs on a HIP device only")
+    lengths = lengths.to(torch.int64).contiguous()
+    out = torch.empty((lengths.numel(),), dtype=torch.int32, device=lengths.device)
+    with torch.cuda.device(lengths.device):
+        stream = torch.cuda.current_stream(lengths.device).cuda_stream
+        capi.check(capi.load().eec_encoder_lengths(lengths.data_ptr(), lengths.numel(), int(t_out), out.data_ptr(),
+                                                   C.c_void_p(stream)), "eec_encoder_lengths")
+    return out
+
+
 def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
     """[N, T', V] fp32 log-probs on the GPU -> (tokens [N, T'] int32, counts [N] int32)."""
     if not logp.is_cuda:

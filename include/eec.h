@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 6
+#define EEC_ABI_VERSION 7
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -45,7 +45,7 @@ enum {
  * flags util/conf.py --d_model --n_heads --d_feed_forward --depthwise_kernel_size
  * --n_enc_exits --n_enc_layers_per_exit --n_mels, dec_voc_size, --max_len). */
 typedef struct eec_config {
-  int32_t d_model;         /* 256 in this build */
+  int32_t d_model;         /* 256 or 512 (64-row / 32-row tile geometry) */
   int32_t n_heads;         /* d_model / n_heads in {32, 64} */
   int32_t d_ff;            /* multiple of 32 */
   int32_t dw_kernel;       /* odd, <= 31 */
@@ -114,6 +114,12 @@ int eec_abi_version(void);
 
 /* T' = ((T-3)/2+1 - 3)/2 + 1 : frames after the two stride-2 convs (early_exit.py:24-48). */
 int eec_out_frames(int T);
+
+/* The length -> key-mask arithmetic of Early_conformer.forward (early_exit.py:623) on its own:
+ *   enc_len[b] = int32( min( float(lengths[b]) / 4, float(T') ) )      (true division in fp32, clamp, truncation)
+ * keys t >= enc_len[b] are masked in every attention of the stack (torchaudio _lengths_to_padding_mask).  The forward
+ * entry points compute it internally; this entry exposes the integers (tests compare them bit for bit). */
+int eec_encoder_lengths(const int64_t* lengths, int B, int Tq, int32_t* enc_len, void* stream);
 
 /* Replaces Early_conformer.__init__ (early_exit.py:567-615) for the encoder stack. */
 int eec_encoder_create(const eec_config* cfg, eec_encoder** out);

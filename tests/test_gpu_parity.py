@@ -41,12 +41,24 @@ def run_gpu(model, mel, lens, prec="f16f8"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 6
+    assert lib.eec_abi_version() == 7
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
+def logp_tolerance(prec, want_logp):
+    """Tolerance policy (README / INTEGRATION.md): |dlogp| <= TOL[prec] * max(1, max|logp| / LOGP_UNIT).  The operand
+    rounding of a mode is a RELATIVE error on the logits, so the absolute log-prob error grows with the logit scale;
+    near-uniform outputs (|logp| <= ~8: random-init heads, log 256 = 5.5) get the flat north-star tolerance, peaky ones
+    (trained / x8 heads: |logp| up to 40) the same bound relative to their scale."""
+    return TOL[prec] * max(1.0, float(np.abs(want_logp).max()) / LOGP_UNIT)
+
+
+LOGP_UNIT = 8.0
+ERR_REPORT = {}
+
+
 @pytest.mark.parametrize("prec", ["f16f8", "f16x3", "mixed", "f16"])
-@pytest.mark.parametrize("name", ["small", "small_h4_k7", "config1"])
+@pytest.mark.parametrize("name", ["small", "small_h4_k7", "config1", "config1_peaky", "config3_small", "config3"])
 def test_golden_logprobs(name, prec):
     """Committed fixtures made by the reference's own Early_conformer class body (make_golden.py)."""
     z, kw = load_golden(name)
@@ -58,10 +70,16 @@ def test_golden_logprobs(name, prec):
     out = run_gpu(gpu, mel, torch.from_numpy(z["lengths"]), prec)
     assert out.shape[:2] == z["logp"].shape[:2] and not torch.isnan(out).any()
     err = np.abs(out[:, :, ::int(z["stride"])].numpy() - z["logp"]).max()
-    assert err < TOL[prec], f"{name}/{prec}: max|dlogp| {err:.3e}"
+    scale = float(np.abs(z["logp"]).max())
+    ERR_REPORT[(name, prec)] = (err, scale)
+    print(f"\n[parity] {name:14s} {prec:6s} max|dlogp| {err:.3e}  max|logp| {scale:6.2f}  err/scale {err / scale:.2e}  "
+          f"tolerance {logp_tolerance(prec, z['logp']):.2e}")
+    assert err < logp_tolerance(prec, z["logp"]), f"{name}/{prec}: max|dlogp| {err:.3e} at max|logp| {scale:.1f}"
+    if name != "config1_peaky":  # the flat north-star tolerance holds outright on every near-uniform fixture
+        assert err < TOL[prec]
     # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only)
     assert np.allclose([out[e].double().sum().item() for e in range(out.size(0))], z["checksum"],
-                       rtol=0, atol=TOL[prec] * out[0].numel() * 0.05)
+                       rtol=0, atol=logp_tolerance(prec, z["logp"]) * out[0].numel() * 0.05)
 
 
 def test_golden_greedy_decode_exact():
@@ -328,7 +346,7 @@ def test_error_paths():
         gpu(torch.zeros(1, 80, 403).cuda(), torch.tensor([403]))  # T' = 99 > 40
     with pytest.raises(RuntimeError, match="HIP device only"):
         gpu(torch.zeros(1, 80, 99), torch.tensor([99]))
-    with pytest.raises(RuntimeError, match="unsupported|256"):
+    with pytest.raises(RuntimeError, match="unsupported|256 or 512"):
         Early_conformer(**base_kwargs(d_model=128, n_head=4, device="cuda")).eval().cuda()(torch.zeros(1, 80, 99).cuda(), torch.tensor([99]))
     gpu.train()
     with pytest.raises(NotImplementedError):
@@ -447,3 +465,228 @@ def test_zipformer_golden(prec):
         want = ref(mel, lens)
     check(run_gpu(gpu, mel, lens, prec), want)
     assert torch.equal(run_gpu(gpu, mel, lens, prec), run_gpu(gpu, mel, lens, prec))  # deterministic
+
+
+def test_stem_dynamic_range():
+    """The reference feeds UN-LOGGED power mel (util/data_loader.py:7-18): heavy-tailed, no upper bound.  The stem's
+    fp16 hi/lo operands live in a per-utterance power-of-two scaled domain chosen from the utterance's maximum, so loud
+    utterances (1e6 - 1e7) do not saturate and quiet ones (1e-8) in the same batch keep their precision."""
+    kw = base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=256)
+    ref, gpu = make_pair(kw, seed=17)
+    B, T = 4, 259
+    base = synth.synth_mel(B, 80, T, seed=17)
+    mel = base.clone()
+    mel[0] *= 1e3                      # up to 1e7
+    mel[1] = mel[1] * 1e-6             # down to ~1e-8 and below
+    mel[2, :, 100:110] = 3.0e6         # a loud burst inside an otherwise ordinary utterance
+    mel[3, 5, 17] = 9.9e6              # a single outlier bin
+    lens = torch.tensor([T, T, 200, 131])
+    with torch.no_grad():
+        want_x = ref.stem(mel)
+        want = ref(mel, lens)
+    for prec in ("f16f8", "f16x3"):
+        gpu.precision = prec
+        with torch.no_grad():
+            x = gpu._run_encoder(mel.cuda(), lens, want_out=False, stop_after=0, want_x=True)[2].cpu()
+        rel = ((x - want_x).abs().amax(dim=(1, 2)) / want_x.abs().amax(dim=(1, 2))).tolist()
+        assert max(rel) < 2e-5, rel  # per utterance, relative to that utterance's own scale
+        got = run_gpu(gpu, mel, lens, prec)
+        assert torch.isfinite(got).all()
+        assert (got - want).abs().max().item() < logp_tolerance(prec, want.numpy())
+
+
+def test_encoder_lengths_bit_exact():
+    """clamp(lengths / 4, max=T').to(int) -- true division in fp32, then truncation
+    (early_exit.py:623) -- as integers, on the device."""
+    from early_exit_transformer_amd.model import encoder_lengths
+    g = np.random.default_rng(3)
+    for Tq in (1, 99, 256, 2000):
+        lens = np.concatenate([np.arange(0, 70), g.integers(0, 4 * Tq + 50, 500), [4 * Tq - 1, 4 * Tq, 4 * Tq + 1, 2 ** 24 + 1, 2 ** 31 + 5]])
+        lt = torch.from_numpy(lens.astype(np.int64))
+        want = R.encoder_lengths(lt, Tq)
+        got = encoder_lengths(lt.cuda(), Tq).cpu()
+        assert got.dtype == torch.int32 and torch.equal(got, want.to(torch.int32))
+
+
+def test_aed_greedy_tokens_golden():
+    """BASELINE config 5 substitute: greedy (beam = 1) AED decode for EVERY exit, B = 1, default 6 x 2 model
+    with 6 decoder layers, as inference.py:44-51 drives it: ``_encoder_`` on the HIP path, ``_decoder_`` (the reference's
+    nn.TransformerDecoder) on PyTorch-ROCm.  Fixture: the reference's own full_conformer run on CPU.  Tokens must be
+    identical up to the first step whose top-2 margin in the fixture is below the safety margin."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    z = np.load(os.path.join(GOLDEN, "aed_greedy.npz"))
+    kw = eval(str(z["kwargs"]))
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=int(z["n_dec_layers"]), **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, int(z["seed"])), strict=True)
+    fc = fc.cuda()
+    fc.device = "cuda"
+    SAFE = 2e-2
+    compared = total = 0
+    for i, (T, seed) in enumerate(eval(str(z["cases"]))):
+        mel, lengths = synth.synth_mel(1, 80, T, seed=seed).cuda(), torch.tensor([T])
+        for n in range(1, kw["n_enc_exits"] + 1):
+            want, margin = z[f"tokens{i}"][n - 1].tolist(), z[f"margin{i}"][n - 1]
+            with torch.no_grad():
+                enc = fc._encoder_(mel, lengths, n)
+                tokens = torch.tensor([[1]], dtype=torch.long, device="cuda")
+                for _ in range(G.aed_max_length(T)):
+                    nxt = fc._decoder_(tokens, enc, n)[:, -1].argmax(-1, keepdim=True)
+                    tokens = torch.cat([tokens, nxt], dim=1)
+            got = tokens[0].tolist()
+            unsafe = np.nonzero(margin < SAFE)[0]
+            upto = 1 + (int(unsafe[0]) if len(unsafe) else len(margin))  # tokens[0] is SOS; step k writes tokens[k + 1]
+            assert got[:upto] == want[:upto], f"case {i} exit {n}: {got} vs {want}"
+            compared += upto - 1
+            total += len(margin)
+    assert compared >= 0.8 * total, f"only {compared}/{total} decode steps had safe margins"
+
+
+def _product_rank(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    from early_exit_transformer_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of this box: gloo, not RCCL
+    try:
+        kw = base_kwargs(n_enc_exits=3, n_enc_layers=1, d_feed_forward=256)
+        gpu = Early_conformer(**{**kw, "device": "cuda"}).eval()
+        gpu.load_state_dict(synth.synth_state_dict(gpu.state_dict(), seed=3, style="trained"))
+        gpu = gpu.cuda()
+        B, T = 5, 259  # uneven shards: 3 + 2
+        mel, lens = synth.synth_mel(B, 80, T, seed=3), torch.tensor([259, 200, 131, 259, 77])
+        tgt, tl = synth.synth_targets(B, 12, 256, seed=3)
+        lo, hi = parallel.shard_range(B, rank, world)
+        with torch.no_grad():
+            local = exit_ctc_losses(gpu(mel[lo:hi].cuda(), lens[lo:hi]), tgt[lo:hi], tl[lo:hi])
+            combined = parallel.combine_exit_losses(local.cpu(), hi - lo)
+            if rank == 0:
+                full = exit_ctc_losses(gpu(mel.cuda(), lens), tgt, tl).cpu()
+                q.put((combined.tolist(), full.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_product_path_sharded_exit_loss():
+    """SURVEY 8e on the PRODUCT path: two ranks (sharing this box's one GPU, so the exchange runs over gloo), each the
+    drop-in module + exit_ctc_losses on its utterance shard, combined by parallel.combine_exit_losses, against the
+    single-process full batch."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_product_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    combined, full = q.get(timeout=300)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert combined == pytest.approx(full, rel=1e-5, abs=1e-5)
+
+
+# ---------------------------------------------------------------------------
+# d_model = 512 (BASELINE.json configs[2]: 18 layers, 8 heads -> head dim 64): the 32-row tile geometry
+# ---------------------------------------------------------------------------
+D512 = dict(d_model=512, n_head=8)
+
+
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "f16"])
+def test_d512_every_substep_against_oracle(prec):
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=2, d_feed_forward=512, **D512)
+    ref, gpu = make_pair(kw, seed=41)
+    mel, lens = synth.synth_mel(3, 80, 203, seed=41), torch.tensor([203, 150, 99])
+    with torch.no_grad():
+        steps = R.trace_substeps(ref, mel, lens)
+    gpu.precision = prec
+    for k, want in enumerate(steps):
+        with torch.no_grad():
+            x = gpu._run_encoder(mel.cuda(), lens, want_out=False, stop_after=k, want_x=True)[2].cpu()
+        scale = want.abs().max().item()
+        err = (x - want).abs().max().item()
+        assert err < {"f16x3": 2e-4, "f16f8": 4e-4, "f16": 2e-3}[prec] * max(scale, 1.0), f"sub-step {k}: {err:.3e} (scale {scale:.2f})"
+
+
+@pytest.mark.parametrize("prec", ["f16f8", "f16x3", "mixed", "f16"])
+def test_d512_fused_plan_equals_substep_plan(prec):
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=3, d_feed_forward=640, **D512)  # 5 chunks of 128
+    _, gpu = make_pair(kw, seed=42)
+    mel, lens = synth.synth_mel(5, 80, 403, seed=42), torch.tensor([403, 402, 300, 77, 5])  # M = 495: ragged last tile
+    gpu.precision = prec
+    with torch.no_grad():
+        out_f, _, x_f = gpu._run_encoder(mel.cuda(), lens, want_x=True)
+        out_s, _, x_s = gpu._run_encoder(mel.cuda(), lens, stop_after=1 + 4 * 6, want_x=True)
+    out_f, x_f, out_s, x_s = out_f.cpu(), x_f.cpu(), out_s.cpu(), x_s.cpu()
+    assert torch.isfinite(x_f).all() and torch.isfinite(out_f).all()
+    assert (x_f - x_s).abs().max().item() < 2e-5 * max(x_s.abs().max().item(), 1.0)
+    assert (out_f - out_s).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("B,T,lens", [(1, 7, [7]), (1, 131, [131]), (5, 403, [403, 402, 300, 77, 5]), (2, 1100, [1100, 640]),
+                                      (4, 61, [1, 8, 61, 3])])
+def test_d512_ragged_shapes(B, T, lens):
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256, **D512)
+    ref, gpu = make_pair(kw, seed=43)
+    mel, lt = synth.synth_mel(B, 80, T, seed=43), torch.tensor(lens)
+    with torch.no_grad():
+        want = ref(mel, lt)
+    for prec in ("f16f8", "f16x3"):
+        got = run_gpu(gpu, mel, lt, prec)
+        assert got.shape == want.shape
+        assert (got - want).abs().max().item() < TOL[prec], prec
+        assert torch.allclose(got.exp().sum(-1), torch.ones(got.shape[:-1]), atol=1e-4)
+
+
+@pytest.mark.parametrize("over", [dict(n_head=16), dict(depthwise_kernel_size=7), dict(d_feed_forward=96), dict(dec_voc_size=96),
+                                  dict(features_length=48)])
+def test_d512_config_surface(over):
+    kw = base_kwargs(**{**dict(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256, **D512), **over})
+    ref, gpu = make_pair(kw, seed=44)
+    nm = kw["features_length"]
+    mel, lens = synth.synth_mel(2, nm, 179, seed=44), torch.tensor([179, 120])
+    with torch.no_grad():
+        want = ref(mel, lens)
+    assert (run_gpu(gpu, mel, lens, "f16x3") - want).abs().max().item() < TOL["f16x3"]
+
+
+class TestConfig3FullSize:
+    """BASELINE.json configs[2] geometry at full size: 6 exits x 3 layers, d_model 512, B = 64, T = 1027 -> T' = 256
+    (forward + fused per-exit CTC losses on HIP); size-independent properties + a subset against the oracle."""
+
+    @pytest.fixture(scope="class")
+    def setup(self):
+        kw = base_kwargs(n_enc_layers=3, **D512)
+        ref, gpu = make_pair(kw, seed=5, style="trained")
+        mel = synth.synth_mel(64, 80, 1027, seed=5)
+        lens = synth.synth_lengths(64, 1027, seed=5)
+        out = run_gpu(gpu, mel, lens)
+        return ref, gpu, mel, lens, out
+
+    def test_normalised_finite_deterministic(self, setup):
+        _, gpu, mel, lens, out = setup
+        assert out.shape == (6, 64, 256, 256) and torch.isfinite(out).all()
+        assert torch.allclose(out.exp().sum(-1), torch.ones(6, 64, 256), atol=2e-4)
+        assert torch.equal(run_gpu(gpu, mel, lens), out)
+
+    def test_utterances_are_independent(self, setup):
+        _, gpu, mel, lens, out = setup
+        assert torch.equal(run_gpu(gpu, mel[40:44], lens[40:44]), out[:, 40:44])
+
+    def test_subset_against_oracle(self, setup):
+        ref, gpu, mel, lens, out = setup
+        idx = [0, 17, 63]
+        with torch.no_grad():
+            want = ref(mel[idx], lens[idx])
+        assert (out[:, idx] - want).abs().max().item() < TOL["f16f8"]
+        got3 = run_gpu(gpu, mel, lens, "f16x3")
+        assert (got3[:, idx] - want).abs().max().item() < TOL["f16x3"]
+
+    def test_fused_exit_losses(self, setup):
+        _, _, _, _, out = setup
+        tgt, tl = synth.synth_targets(64, 42, 256, seed=5)
+        got = exit_ctc_losses(out.cuda(), tgt, tl).cpu()
+        want = torch.stack([R.summed_exit_ctc_loss(out[e:e + 1], tgt, tl) for e in range(6)])
+        assert torch.allclose(got, want, rtol=2e-5, atol=2e-5)

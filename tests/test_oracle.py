@@ -214,3 +214,64 @@ def test_trace_substeps_ends_at_forward_taps():
         steps = R.trace_substeps(m, mel, lens)
         _, taps = m(mel, lens, return_taps=True)
     assert len(steps) == 1 + 4 * 2 and torch.equal(steps[4], taps[0]) and torch.equal(steps[8], taps[1])
+
+
+def test_oracle_conformer_layer_matches_independent_published_block():
+    """The torchaudio half of the oracle has no reference-held vectors.  The only independent, offline check
+    of the restated block ordering: Hugging Face's ``Wav2Vec2ConformerEncoderLayer`` (transformers, installed from the
+    wheelhouse) is a separately written Conformer block with the same published structure -- macaron feed-forwards x 0.5,
+    LayerNorm -> MHSA, LN -> pointwise -> GLU -> depthwise -> BatchNorm -> swish -> pointwise, final LayerNorm.  With the
+    same weights (its convolutions carry no bias: the oracle's are zeroed; position embeddings off) the two must agree.
+    This does not pin torchaudio itself; it pins the ordering / scaling constants the oracle restates."""
+    # the stand-in torchaudio modules other tests bind for the reference import have no __spec__: transformers'
+    # availability probes trip over them, so they are set aside while it imports
+    stubs = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "torchaudio" or k.startswith("torchaudio.")}
+    try:
+        tr = pytest.importorskip("transformers")
+        from transformers.models.wav2vec2_conformer.modeling_wav2vec2_conformer import Wav2Vec2ConformerEncoderLayer
+    finally:
+        sys.modules.update(stubs)
+    D, H, F, K = 64, 4, 160, 7
+    cfg = tr.Wav2Vec2ConformerConfig(hidden_size=D, num_attention_heads=H, intermediate_size=F, conv_depthwise_kernel_size=K,
+                                     hidden_act="swish", position_embeddings_type=None, attention_dropout=0.0,
+                                     activation_dropout=0.0, hidden_dropout=0.0, conformer_conv_dropout=0.0)
+    hf = Wav2Vec2ConformerEncoderLayer(cfg).eval()
+    mine = R.ConformerLayer(D, F, H, K, dropout=0.0).eval()
+    sd = synth.synth_state_dict(mine.state_dict(), seed=77, style="trained")
+    for k in ("conv_module.sequential.0.bias", "conv_module.sequential.2.bias", "conv_module.sequential.5.bias"):
+        sd[k] = torch.zeros_like(sd[k])
+    mine.load_state_dict(sd)
+    wq, wk, wv = sd["self_attn.in_proj_weight"].chunk(3)
+    bq, bk, bv = sd["self_attn.in_proj_bias"].chunk(3)
+    hf_sd = {
+        "ffn1_layer_norm.weight": sd["ffn1.sequential.0.weight"], "ffn1_layer_norm.bias": sd["ffn1.sequential.0.bias"],
+        "ffn1.intermediate_dense.weight": sd["ffn1.sequential.1.weight"], "ffn1.intermediate_dense.bias": sd["ffn1.sequential.1.bias"],
+        "ffn1.output_dense.weight": sd["ffn1.sequential.4.weight"], "ffn1.output_dense.bias": sd["ffn1.sequential.4.bias"],
+        "self_attn_layer_norm.weight": sd["self_attn_layer_norm.weight"], "self_attn_layer_norm.bias": sd["self_attn_layer_norm.bias"],
+        "self_attn.linear_q.weight": wq, "self_attn.linear_q.bias": bq, "self_attn.linear_k.weight": wk,
+        "self_attn.linear_k.bias": bk, "self_attn.linear_v.weight": wv, "self_attn.linear_v.bias": bv,
+        "self_attn.linear_out.weight": sd["self_attn.out_proj.weight"], "self_attn.linear_out.bias": sd["self_attn.out_proj.bias"],
+        "conv_module.layer_norm.weight": sd["conv_module.layer_norm.weight"], "conv_module.layer_norm.bias": sd["conv_module.layer_norm.bias"],
+        "conv_module.pointwise_conv1.weight": sd["conv_module.sequential.0.weight"],
+        "conv_module.depthwise_conv.weight": sd["conv_module.sequential.2.weight"],
+        "conv_module.batch_norm.weight": sd["conv_module.sequential.3.weight"], "conv_module.batch_norm.bias": sd["conv_module.sequential.3.bias"],
+        "conv_module.batch_norm.running_mean": sd["conv_module.sequential.3.running_mean"],
+        "conv_module.batch_norm.running_var": sd["conv_module.sequential.3.running_var"],
+        "conv_module.batch_norm.num_batches_tracked": sd["conv_module.sequential.3.num_batches_tracked"],
+        "conv_module.pointwise_conv2.weight": sd["conv_module.sequential.5.weight"],
+        "ffn2_layer_norm.weight": sd["ffn2.sequential.0.weight"], "ffn2_layer_norm.bias": sd["ffn2.sequential.0.bias"],
+        "ffn2.intermediate_dense.weight": sd["ffn2.sequential.1.weight"], "ffn2.intermediate_dense.bias": sd["ffn2.sequential.1.bias"],
+        "ffn2.output_dense.weight": sd["ffn2.sequential.4.weight"], "ffn2.output_dense.bias": sd["ffn2.sequential.4.bias"],
+        "final_layer_norm.weight": sd["final_layer_norm.weight"], "final_layer_norm.bias": sd["final_layer_norm.bias"],
+    }
+    missing, unexpected = hf.load_state_dict(hf_sd, strict=False)
+    assert not unexpected and not [m for m in missing if "pos_bias" not in m and "linear_pos" not in m], (missing, unexpected)
+    B, T = 3, 29
+    x = torch.from_numpy(synth.normal(5, "x", B * T * D).astype(np.float32)).reshape(B, T, D)
+    lens = torch.tensor([29, 17, 8])
+    pad = R.lengths_to_padding_mask(lens)  # True = padding
+    add_mask = torch.zeros(B, 1, T, T).masked_fill(pad[:, None, None, :], float("-inf"))  # keys only, like torchaudio
+    with torch.no_grad():
+        want = hf(x, attention_mask=add_mask)[0]
+        got = mine(x.transpose(0, 1), pad).transpose(0, 1)
+    assert (got - want).abs().max().item() < 2e-5
