@@ -42,8 +42,8 @@ CFG = dict(src_pad_idx=0, n_enc_exits=6, enc_voc_size=256, dec_voc_size=256, d_m
            d_feed_forward=2048, n_enc_layers=2, features_length=80, drop_prob=0.1, depthwise_kernel_size=31)
 
 
-def flops_per_forward(B, T):
-    D, F, K, E, L, V, NM = 256, 2048, 31, 6, 2, 256, 80
+def flops_per_forward(B, T, D=256, L=2):
+    F, K, E, V, NM = 2048, 31, 6, 256, 80
     T1 = (T - 3) // 2 + 1
     Tq = (T1 - 3) // 2 + 1
     mac_frame = E * L * (4 * D * F + 7 * D * D + K * D + 2 * Tq * D) + E * D * V + 3 * D * D + 3 * NM * D * T1 / Tq
@@ -238,6 +238,35 @@ def main():
         d = time.perf_counter() - t1
         forward_only = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4)}
 
+    # ---- BASELINE.json configs[2] geometry (secondary line): 6 exits x 3 layers, d_model 512, forward + fused exit losses ----
+    config3 = None
+    if rank == 0 and world == 1 and not args.no_modes:
+        cfg3 = dict(CFG, d_model=512, n_enc_layers=3)
+        m3 = Early_conformer(device=dev, **cfg3).eval()
+        m3.load_state_dict(synth.synth_state_dict(m3.state_dict(), seed=1, style="init"))
+        m3 = m3.to(dev)
+        m3.precision = args.precision
+
+        def run3(n):
+            for _ in range(n):
+                with torch.no_grad():
+                    exit_ctc_losses(m3(mel, lengths), tgt, tgt_len)
+        run3(3)
+        torch.cuda.synchronize()
+        n3 = max(5, args.steps // 2)
+        t1 = time.perf_counter()
+        run3(n3)
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t1) / n3
+        f3, _ = flops_per_forward(B, T, D=512, L=3)
+        config3 = {"workload": f"early_conformer ctc 18-layer d_model=512 (6 exits x 3, 8 heads x 64), batch {B}, mel [80 x {T}], "
+                               "forward + fused per-exit CTC losses (BASELINE.json configs[2] geometry; no backward yet)",
+                   "value": round(B * T / d, 1), "unit": "mel-frames/s", "ms_per_step": round(d * 1e3, 4),
+                   "algorithmic_flop_per_forward": f3, "frac_of_mfma_peak": round(f3 / d / MFMA_PEAK_FLOPS, 4),
+                   "precision_mode": args.precision}
+        del m3
+        torch.cuda.empty_cache()
+
     # HBM-side bytes per FFN launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
     # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
@@ -362,7 +391,7 @@ def main():
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
-            "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary,
+            "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

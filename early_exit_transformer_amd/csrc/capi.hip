@@ -64,7 +64,6 @@ size_t f8_u4(int N, int K) { return (size_t)((N + 31) / 32) * ((K + 63) / 64) * 
 
 }  // namespace
 
-constexpr int kMaxStem1Batch = 4096;
 enum KernelClass { KC_STEM = 0, KC_FFN, KC_QKV, KC_ATTN, KC_PROJ_GLU, KC_PROJ, KC_DW_PW2, KC_HEAD, KC_CHAIN, KC_COUNT };
 
 struct eec_encoder {
@@ -83,7 +82,6 @@ struct eec_encoder {
   std::vector<PackedLayer> layers;
   uint4 *sub_w1p, *sub_w2p;
   float *sub_b1, *sub_b2, *pe;
-  int* stem_e;  // [kMaxStem1Batch] per-utterance scale exponents of eec_encoder_stem1_forward (the full forward keeps its own in the workspace)
   std::vector<uint4*> head_p;
   std::vector<float*> head_b;
 
@@ -129,7 +127,6 @@ struct eec_encoder {
     sub_w2p = arena.take<uint4>(frag_u4(D, 3 * D));
     sub_b2 = arena.take<float>(D);
     pe = arena.take<float>((size_t)cfg.max_len * D);
-    stem_e = arena.take<int>(kMaxStem1Batch);
     head_p.assign(cfg.n_exits, nullptr);
     head_b.assign(cfg.n_exits, nullptr);
     for (int e = 0; e < cfg.n_exits; ++e) {
@@ -146,7 +143,7 @@ struct Workspace {
   float* x;
   float* y;  // [(E-1)][M][256]: exit rows for the batched head launch when the caller passes no tap buffer
   half_t *mid_hi, *mid_lo, *q, *k, *vt, *p_hi, *p_lo, *g;
-  int *enc_len, *mel_e;
+  int *enc_len, *mid_e;
   size_t bytes;
 };
 
@@ -167,7 +164,7 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   w.p_lo = a.take<half_t>(M * D);
   w.g = a.take<half_t>(M * D);
   w.enc_len = a.take<int>(B);
-  w.mel_e = a.take<int>(B);
+  w.mid_e = a.take<int>((size_t)B * T1);
   w.bytes = align_up(a.off);
   return w;
 }
@@ -511,7 +508,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   EEC_HIP(launch_enc_lengths((const long long*)lengths, B, Tq, ws.enc_len, st));
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   {
-    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, D, ws.mel_e, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
+    SubsampleArgs a{mel, B, c.n_mels, T, T1, Tq, D, ws.mid_e, enc->sub_w1p, enc->sub_b1, enc->sub_w2p, enc->sub_b2, enc->pe, ws.mid_hi, ws.mid_lo, ws.x};
     TIMED(KC_STEM, launch_subsample(a, 3, st));  // raw power mel: always hi/lo split (1 % of the flops)
   }
   ++step;
@@ -718,8 +715,7 @@ int eec_encoder_stem1_forward(eec_encoder* enc, const float* mel, int B, int T, 
   const int T1 = (T - 3) / 2 + 1;
   if (T1 > c.max_len) return fail(EEC_ERR_BAD_ARG, "T1 exceeds the positional-encoding table (max_len)");
   hipStream_t st = (hipStream_t)stream;
-  if (B > kMaxStem1Batch) return fail(EEC_ERR_UNSUPPORTED, "stem1: batch above 4096");
-  SubsampleArgs a{mel, B, c.n_mels, T, T1, T1, c.d_model, enc->stem_e, enc->sub_w1p, enc->sub_b1, nullptr, nullptr, enc->pe, nullptr, nullptr, x};
+  SubsampleArgs a{mel, B, c.n_mels, T, T1, T1, c.d_model, nullptr, enc->sub_w1p, enc->sub_b1, nullptr, nullptr, enc->pe, nullptr, nullptr, x};
   TIMED(KC_STEM, launch_subsample_single(a, st));
   return 0;
 }

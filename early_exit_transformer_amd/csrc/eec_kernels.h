@@ -123,7 +123,7 @@ hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tai
 struct SubsampleArgs {
   const float* mel;  // [B][n_mels][T]
   int B, n_mels, T, T1, Tq, D;
-  int* mel_e;        // [B]: per-utterance power-of-two exponent of the scaled fp16 domain (written by the stem launch)
+  int* mid_e;        // [B*T1]: power-of-two exponent of every conv1 output row's scaled fp16 domain (scratch; unused by the one-conv stem)
   const uint4* w1p;       // packed conv1 weight as [256][n_mels*3] (its own [ci][j] flattening)
   const float* b1;
   const uint4* w2p;       // packed conv2 weight as [256][3*256], k ordered (j, ci)

@@ -6,12 +6,13 @@
 //          A[row][3ci + j] = mel[b][ci][2 t1 + j]                       -> mid (scaled, fp16 planes)
 //   conv2: rows = (b, t'), K = 3*D as three K=D passes j = 0..2,
 //          A_j[row][ci] = mid[b][2 t' + j][ci]  (2 R + 1 staged frames, lane row stride 2)
-// The input is un-logged power mel (util/data_loader.py:7-18: heavy-tailed, no upper bound).  fp16 operands need a
-// bounded domain, so every UTTERANCE gets a power-of-two scale 2^-e_b (exact) from its own maximum,
-//     e_b = max(6, exponent(max |mel[b]|) - 10)        (the scaled values stay below 2^10),
-// mid stays in that scaled domain and the final accumulators are multiplied by 2^e_b.  Up to a maximum of 65536 this is
-// the fixed 2^-6 every fixture was generated with; louder utterances no longer saturate the fp16 cast, and one loud
-// utterance does not cost the quiet ones of its batch their precision.
+// The input is un-logged power mel (util/data_loader.py:7-18: heavy-tailed, no upper bound, 5+ decades between the loud
+// and the quiet frames of one utterance).  fp16 operands need a bounded domain, so every ROW of a product gets its own
+// power-of-two scale (exact): a conv1 row (the 3-frame window of one half-rate frame) is multiplied by 2^-e,
+// e = exponent(max |window|) - 15, and its fp32 accumulators by 2^e; the conv1 output row is stored as fp16 hi/lo planes
+// in a scaled domain of ITS own (exponent array mid_e[B*T1]); conv2 sums three mid rows per output frame, one K = D pass
+// each, and rescales the accumulators (lane = output frame) by 2^(e_j - e_(j+1)) between the passes.  One outlier bin or
+// one loud utterance therefore costs no other frame its precision, and nothing saturates up to fp32's own range.
 #include "eec_kernels.h"
 #include "eec_blocks.h"
 
@@ -20,27 +21,13 @@ namespace eec {
 constexpr int kStemThreads = 512;
 constexpr int kStemRows1 = 64;  // conv1 row tile: (utterance, frame) rows of the half-rate sequence
 constexpr int kSPF = 4;
-constexpr int kMelExpMin = 6;
 
-// e_b of every utterance: one workgroup per utterance, max |x| over n_mels * T values.
-__global__ __launch_bounds__(256) void mel_exponent_kernel(const float* __restrict__ mel, int per_utt, int* __restrict__ mel_e) {
-  __shared__ float part[4];
-  const float* src = mel + (size_t)blockIdx.x * per_utt;
-  float m = 0.f;
-  for (int i = threadIdx.x; i < per_utt; i += 256) m = fmaxf(m, fabsf(src[i]));
-  m = wave_max(m);
-  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    int e = kMelExpMin;
-    if (m > 0.f && m < INFINITY) {
-      int ex;
-      (void)frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
-      e = max(kMelExpMin, ex - 10);
-    }
-    mel_e[blockIdx.x] = e;
-  }
+// exponent e such that |m| * 2^-e < 2^15 (m = a row's maximum magnitude); 0 for an all-zero / non-finite row
+__device__ __forceinline__ int row_exponent(float m) {
+  if (!(m > 0.f) || !(m < INFINITY)) return 0;
+  int ex;
+  (void)frexpf(m, &ex);  // m = f * 2^ex, f in [0.5, 1)
+  return ex - 15;
 }
 
 // ---------------------------------------------------------------------------
@@ -61,39 +48,56 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleAr
   const uint4* w_lane = a.w1p + (size_t)(NW * w) * ks * 128 + lane;
   const size_t nts = (size_t)ks * 128;
   ring_fill<NP, kSPF, NW>(r, w_lane, nts, ks);
-  // stage A: thread = (row r, channel group); 3 taps per (row, ci)
+  unsigned* row_max = (unsigned*)(smem + 2 * plane);  // [64] input rows, [64] output rows: |max| as fp32 bit patterns
+  if (threadIdx.x < 2 * kStemRows1) row_max[threadIdx.x] = 0u;
+  // stage A: thread = (row rr, channel group cg); 3 taps per (row, ci); the row's scale comes from its own maximum
   {
     const int rr = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int row = row0 + rr;
     const bool ok = row < M1;
     const int b = ok ? row / a.T1 : 0, t1 = ok ? row - b * a.T1 : 0;
-    const float sc = ldexpf(1.0f, -a.mel_e[b]);
     const float* src = a.mel + (size_t)b * a.n_mels * a.T + 2 * t1;
-    for (int ci = cg; ci < a.n_mels; ci += 8) {
-      float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-      if (ok) {
+    constexpr int CI = 16;  // channels per thread: n_mels <= 128
+    float v[CI][3];
+    float m = 0.f;
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const int ci = cg + 8 * i;
+      v[i][0] = v[i][1] = v[i][2] = 0.f;
+      if (ok && ci < a.n_mels) {
         const float* p = src + (size_t)ci * a.T;
-        v0 = p[0] * sc, v1 = p[1] * sc, v2 = p[2] * sc;
+        v[i][0] = p[0], v[i][1] = p[1], v[i][2] = p[2];
       }
-      const hl2_t s01 = split2<NP>(v0, v1), s2 = split2<NP>(v2, 0.f);
-      half_t* dh = (half_t*)(smem + rr * ld) + ci * 3;
-      dh[0] = s01.hi[0], dh[1] = s01.hi[1], dh[2] = s2.hi[0];
-      if (NP == 3) {
-        half_t* dl = (half_t*)(smem + plane + rr * ld) + ci * 3;
-        dl[0] = s01.lo[0], dl[1] = s01.lo[1], dl[2] = s2.lo[0];
+      m = fmaxf(m, fmaxf(fabsf(v[i][0]), fmaxf(fabsf(v[i][1]), fabsf(v[i][2]))));
+    }
+    __syncthreads();  // row_max zeroed
+    atomicMax(&row_max[rr], __builtin_bit_cast(unsigned, m));  // non-negative floats order like their bit patterns
+    __syncthreads();
+    const float sc = ldexpf(1.0f, -row_exponent(__builtin_bit_cast(float, row_max[rr])));
+#pragma unroll
+    for (int i = 0; i < CI; ++i) {
+      const int ci = cg + 8 * i;
+      if (ci < a.n_mels) {
+        const hl2_t s01 = split2<NP>(v[i][0] * sc, v[i][1] * sc), s2 = split2<NP>(v[i][2] * sc, 0.f);
+        half_t* dh = (half_t*)(smem + rr * ld) + ci * 3;
+        dh[0] = s01.hi[0], dh[1] = s01.hi[1], dh[2] = s2.hi[0];
+        if (NP == 3) {
+          half_t* dl = (half_t*)(smem + plane + rr * ld) + ci * 3;
+          dl[0] = s01.lo[0], dl[1] = s01.lo[1], dl[2] = s2.lo[0];
+        }
       }
     }
   }
   __syncthreads();
-  // this lane's two rows, their utterances' scales
+  // this lane's two rows and the exponents of their scaled input domains
   int rowl[2], el[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     rowl[mt] = row0 + mt * 32 + (lane & 31);
-    el[mt] = a.mel_e[min(rowl[mt], M1 - 1) / a.T1];
+    el[mt] = row_exponent(__builtin_bit_cast(float, row_max[mt * 32 + (lane & 31)]));
   }
   f32x16 acc[2][NW];
-  // accumulators start at bias * 2^-e (the scaled domain)
+  // accumulators start at bias * 2^-e (the row's scaled domain)
 #pragma unroll
   for (int nt = 0; nt < NW; ++nt)
 #pragma unroll
@@ -133,18 +137,33 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleAr
     }
     return;
   }
-  // mid planes [B*T1][D] (scaled domain): lane = row, register quad = 4 consecutive channels
+  // the output row's own scaled domain: maximum over its D channels (8 waves x 2 lane halves hold parts of a row)
+  unsigned* out_max = row_max + kStemRows1;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    float m = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, fabsf(acc[mt][nt][i]));
+    atomicMax(&out_max[mt * 32 + (lane & 31)], __builtin_bit_cast(unsigned, m));
+  }
+  __syncthreads();
+  // mid planes [B*T1][D]: lane = row, register quad = 4 consecutive channels; mid_e[row] = exponent of the row's domain
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = rowl[mt];
     if (row < M1) {
+      const int eo = row_exponent(__builtin_bit_cast(float, out_max[mt * 32 + (lane & 31)]));  // relative to the input domain
+      if (w == 0 && hh == 0) a.mid_e[row] = el[mt] + eo;
+      const float sc = ldexpf(1.0f, -eo);
 #pragma unroll
       for (int nt = 0; nt < NW; ++nt) {
         const size_t off = (size_t)row * D + 32 * (NW * w + nt) + 4 * hh;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const hl2_t s0 = split2<NP>(acc[mt][nt][4 * g + 0], acc[mt][nt][4 * g + 1]);
-          const hl2_t s1 = split2<NP>(acc[mt][nt][4 * g + 2], acc[mt][nt][4 * g + 3]);
+          const hl2_t s0 = split2<NP>(acc[mt][nt][4 * g + 0] * sc, acc[mt][nt][4 * g + 1] * sc);
+          const hl2_t s1 = split2<NP>(acc[mt][nt][4 * g + 2] * sc, acc[mt][nt][4 * g + 3] * sc);
           h4 hi, lo;
           hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
           *(h4*)(a.mid_hi + off + 8 * g) = hi;
@@ -194,20 +213,51 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv2_kernel(SubsampleAr
     if (NP == 3) *(uint4*)(smem + plane + fr * S::kLd + c16 * 16) = vl;
   }
   __syncthreads();
-  const int e = a.mel_e[b];
+  // exponents of this lane's three input rows per output frame (mid rows 2 t + j of utterance b)
+  int ej[MT][3];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int t = t0 + mt * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) ej[mt][j] = (2 * t + j < a.T1) ? a.mid_e[(size_t)b * a.T1 + 2 * t + j] : 0;
+  }
   f32x16 acc[MT][NW];
-  acc_init_bias<MT, NW>(acc, a.b2 + 32 * NW * w, ldexpf(1.0f, -e));
+#pragma unroll
+  for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 bb = *(const float4*)(a.b2 + 32 * (NW * w + nt) + 8 * g + 4 * hh);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float sc = ldexpf(1.0f, -ej[mt][0]);
+        acc[mt][nt][4 * g + 0] = bb.x * sc;
+        acc[mt][nt][4 * g + 1] = bb.y * sc;
+        acc[mt][nt][4 * g + 2] = bb.z * sc;
+        acc[mt][nt][4 * g + 3] = bb.w * sc;
+      }
+    }
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const char* a_lane = smem + (2 * (lane & 31) + j) * S::kLd + hh * 16;
     gemm_ring<NP, KS, NW, true, kSPF, NoSide, 0, MT>(acc, a_lane, 2 * S::kLd, plane, w_lane + (size_t)j * KS * 128, nts, r);
-    if (j < 2) ring_fill<NP, kSPF, NW>(r, w_lane + (size_t)(j + 1) * KS * 128, nts, KS);
+    if (j < 2) {
+      ring_fill<NP, kSPF, NW>(r, w_lane + (size_t)(j + 1) * KS * 128, nts, KS);
+      // into the next row's domain (exact: powers of two; the clamp keeps the shift inside ldexp's exact range)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int d = max(-120, min(120, ej[mt][j] - ej[mt][j + 1]));
+#pragma unroll
+        for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = ldexpf(acc[mt][nt][i], d);
+      }
+    }
   }
-  const float up = ldexpf(1.0f, e);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int t = t0 + mt * 32 + (lane & 31);
     if (t < a.Tq) {
+      const float up = ldexpf(1.0f, ej[mt][2]);
 #pragma unroll
       for (int nt = 0; nt < NW; ++nt) {
         const int c0 = 32 * (NW * w + nt) + 4 * hh;
@@ -224,20 +274,14 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv2_kernel(SubsampleAr
   }
 }
 
-static hipError_t launch_mel_exponent(const SubsampleArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(mel_exponent_kernel, dim3(a.B), dim3(256), 0, st, a.mel, a.n_mels * a.T, a.mel_e);
-  return hipGetLastError();
-}
-
 template <int D>
 static hipError_t launch_subsample_d(const SubsampleArgs& a, int np, hipStream_t st) {
   const int K1 = a.n_mels * 3;
-  const int lds1 = 2 * kStemRows1 * (K1 + 8) * 2;
+  const int lds1 = 2 * kStemRows1 * (K1 + 8) * 2 + 2 * kStemRows1 * 4;
   auto k1 = np == 3 ? stem_conv1_kernel<D, 3, false> : stem_conv1_kernel<D, 1, false>;
   auto k2 = np == 3 ? stem_conv2_kernel<D, 3> : stem_conv2_kernel<D, 1>;
-  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kStemRows1 * (384 + 8) * 2); e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kStemRows1 * (384 + 8) * 2 + 2 * kStemRows1 * 4); e != hipSuccess) return e;
   if (hipError_t e = ensure_max_lds((const void*)k2, Stem2Geo<D>::kLds); e != hipSuccess) return e;
-  if (hipError_t e = launch_mel_exponent(a, st); e != hipSuccess) return e;
   const int M1 = a.B * a.T1;
   hipLaunchKernelGGL(k1, dim3((M1 + kStemRows1 - 1) / kStemRows1), dim3(kStemThreads), lds1, st, a);
   hipError_t e = hipGetLastError();
@@ -247,7 +291,7 @@ static hipError_t launch_subsample_d(const SubsampleArgs& a, int np, hipStream_t
 }
 hipError_t launch_subsample(const SubsampleArgs& a, int np, hipStream_t st) {
   const int K1 = a.n_mels * 3;
-  if (K1 % 16 || K1 > 384 || !a.mel_e) return hipErrorInvalidValue;
+  if (K1 % 16 || K1 > 384 || !a.mid_e) return hipErrorInvalidValue;
   return a.D == 512 ? launch_subsample_d<512>(a, np, st) : launch_subsample_d<256>(a, np, st);
 }
 
@@ -256,15 +300,14 @@ template <int D>
 static hipError_t launch_subsample_single_d(const SubsampleArgs& a, hipStream_t st) {
   const int K1 = a.n_mels * 3;
   auto k1 = stem_conv1_kernel<D, 3, true>;
-  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kStemRows1 * (384 + 8) * 2); e != hipSuccess) return e;
-  if (hipError_t e = launch_mel_exponent(a, st); e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kStemRows1 * (384 + 8) * 2 + 2 * kStemRows1 * 4); e != hipSuccess) return e;
   const int M1 = a.B * a.T1;
-  hipLaunchKernelGGL(k1, dim3((M1 + kStemRows1 - 1) / kStemRows1), dim3(kStemThreads), 2 * kStemRows1 * (K1 + 8) * 2, st, a);
+  hipLaunchKernelGGL(k1, dim3((M1 + kStemRows1 - 1) / kStemRows1), dim3(kStemThreads), 2 * kStemRows1 * (K1 + 8) * 2 + 2 * kStemRows1 * 4, st, a);
   return hipGetLastError();
 }
 hipError_t launch_subsample_single(const SubsampleArgs& a, hipStream_t st) {
   const int K1 = a.n_mels * 3;
-  if (K1 % 16 || K1 > 384 || !a.mel_e) return hipErrorInvalidValue;
+  if (K1 % 16 || K1 > 384) return hipErrorInvalidValue;
   return a.D == 512 ? launch_subsample_single_d<512>(a, st) : launch_subsample_single_d<256>(a, st);
 }
 

@@ -77,9 +77,11 @@ def test_golden_logprobs(name, prec):
     assert err < logp_tolerance(prec, z["logp"]), f"{name}/{prec}: max|dlogp| {err:.3e} at max|logp| {scale:.1f}"
     if name != "config1_peaky":  # the flat north-star tolerance holds outright on every near-uniform fixture
         assert err < TOL[prec]
-    # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only)
+    # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only).  A logit error on a row's
+    # dominant class shifts the whole row's log-probs together, so the errors of a row do not average out: the bound is
+    # a quarter of "every element off by the tolerance"
     assert np.allclose([out[e].double().sum().item() for e in range(out.size(0))], z["checksum"],
-                       rtol=0, atol=logp_tolerance(prec, z["logp"]) * out[0].numel() * 0.05)
+                       rtol=0, atol=logp_tolerance(prec, z["logp"]) * out[0].numel() * 0.25)
 
 
 def test_golden_greedy_decode_exact():
@@ -469,8 +471,9 @@ def test_zipformer_golden(prec):
 
 def test_stem_dynamic_range():
     """The reference feeds UN-LOGGED power mel (util/data_loader.py:7-18): heavy-tailed, no upper bound.  The stem's
-    fp16 hi/lo operands live in a per-utterance power-of-two scaled domain chosen from the utterance's maximum, so loud
-    utterances (1e6 - 1e7) do not saturate and quiet ones (1e-8) in the same batch keep their precision."""
+    fp16 hi/lo operands live in per-ROW power-of-two scaled domains chosen from each row's own maximum (stem.hip), so
+    loud frames (1e6 - 1e7) do not saturate and neither a loud utterance nor a single outlier bin costs the quiet frames
+    (1e-8) of the batch their precision."""
     kw = base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=256)
     ref, gpu = make_pair(kw, seed=17)
     B, T = 4, 259
@@ -492,7 +495,9 @@ def test_stem_dynamic_range():
         assert max(rel) < 2e-5, rel  # per utterance, relative to that utterance's own scale
         got = run_gpu(gpu, mel, lens, prec)
         assert torch.isfinite(got).all()
-        assert (got - want).abs().max().item() < logp_tolerance(prec, want.numpy())
+        per_utt = (got - want).abs().amax(dim=(0, 2, 3)).tolist()
+        print(f"\n[stem range] {prec}: stem rel err per utterance {['%.1e' % r for r in rel]}, max|dlogp| per utterance {['%.2e' % e for e in per_utt]}")
+        assert max(per_utt) < logp_tolerance(prec, want.numpy()), per_utt
 
 
 def test_encoder_lengths_bit_exact():
