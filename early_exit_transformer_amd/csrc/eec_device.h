@@ -403,11 +403,16 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 // NW: number of lo8 group buffers.  NW == NG: the whole stage is resident (loaded by the caller one stage ahead);
 // NW < NG: rolling buffers, group g lives in wg[g % NW] and is refilled with group g + NW right after its use
 // (the caller preloads groups 0 .. NW-1 of the next stage).
-template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0, int MT = 2>
+// CONT: the stream CONTINUES into another product of the same shape whose first record (+lane) is `next_lane` (wave-uniform,
+// may be null): the last PF k-steps refill the ring -- and the last NW groups their lo8 buffers -- with that product's first
+// steps / groups, so the caller starts it with a full pipeline and no separate fill.
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0, int MT = 2, bool CONT = false>
 __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
                                              int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
-                                             WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side()) {
+                                             WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side(),
+                                             const uint4* __restrict__ next_lane = nullptr) {
   constexpr int KS = 4 * NG;
+  static_assert(!CONT || (KS % PF == 0 && NG % NW == 0), "a continued stream keeps its ring phase: PF | k-steps, NW | groups");
   auto hi_addr = [&](int s) { return (size_t)(s >> 2) * kF8Rec + (size_t)(s & 3) * 64; };
   h8 ah[2][MT];
 #pragma unroll
@@ -457,6 +462,11 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
 #endif
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = rec_lane[nt * nt_stride + hi_addr(s + PF)];
+    } else if (CONT && next_lane) {
+#ifndef EEC_ABLATE_W
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = next_lane[nt * nt_stride + hi_addr(s + PF - KS)];
+#endif
     }
     if (q == 3) {  // the group's two correction products
 #pragma unroll
@@ -481,6 +491,7 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
         }
       }
       if (NW < NG && g + NW < NG) f8_group_load<NT>(wg[g % NW], rec_lane + (size_t)(g + NW) * kF8Rec, nt_stride);
+      else if (CONT && next_lane) f8_group_load<NT>(wg[g % NW], next_lane + (size_t)(g + NW - NG) * kF8Rec, nt_stride);
     }
     side(s);
     if (SIDE_VALU > 0) {

@@ -59,7 +59,7 @@ template <int D> struct FfnPf<D, 1> { static constexpr int P1 = EEC_PF1_NP1, P2 
 #define EEC_PF1_NP8 6
 #define EEC_PF2_NP8 3
 #endif
-template <int D> struct FfnPf<D, 8> { static constexpr int P1 = EEC_PF1_NP8, P2 = D == 512 ? 2 : EEC_PF2_NP8; };  // hi fragments only ride the ring in the f8 stream
+template <int D> struct FfnPf<D, 8> { static constexpr int P1 = EEC_PF1_NP8, P2 = D == 512 ? 2 : EEC_PF2_NP8; };  // D = 512: continued stream, PF | k-steps  // hi fragments only ride the ring in the f8 stream
 #ifndef EEC_DROP1
 #define EEC_DROP1 0  // diagnostic: correction terms of GEMM1 / GEMM2 to skip (see gemm_ring_f8)
 #define EEC_DROP2 0
@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   constexpr size_t nts = (size_t)KS * 128;  // uint4 between adjacent n-tiles of a K = D matrix
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int kPF1 = FfnPf<D, NP>::P1, kPF2 = FfnPf<D, NP>::P2;
+  // A consumer wave owns NT2 output column tiles.  In the f8 stream more than two tiles per k-step do not fit the register
+  // file (ring + lo8 buffers + e5m2 copies per tile), so at D = 512 a chunk's GEMM2 runs as NH = 2 column passes of
+  // NTP = 2 tiles over the same H chunk, each pass's weight stream continuing into the next (gemm_ring_f8 CONT).
+  constexpr int NH = (NP == 8 && NT2 > 2) ? NT2 / 2 : 1, NTP = NT2 / NH;
   const int lane = lane_id(), w = wave_id();
   const int hh = lane >> 5, wl = w & 3;
   const int w_s = wave_id_sgpr();
@@ -245,12 +249,14 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   auto run = [&](auto prod_tag) {
   constexpr bool producer = decltype(prod_tag)::value;
   WRing<RNP, kPF1, 1> r1;
-  WRing<RNP, kPF2, NT2> r2;
+  WRing<RNP, kPF2, NTP> r2;
   WGroupF8<1> wg1[kNW1];    // NP == 8: lo8 + scales of GEMM1 (K = D = D/64 groups), rolling through kNW1 buffers
-  WGroupF8<NT2> wg2[kNW2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, NT2 n-tiles)
+  WGroupF8<NTP> wg2[kNW2];  //          ... of a whole GEMM2 stage (128 hidden = 2 groups, NTP n-tiles)
   const size_t w2f8_nt = (size_t)(F / 64) * kF8Rec;
   auto w1f8_lane = [&](const WPtrs& W, int ft) { return W.w1f8 + (size_t)ft * (D / 64) * kF8Rec + lane; };
-  auto w2f8_lane = [&](const WPtrs& W, int c) { return W.w2f8 + ((size_t)(NT2 * wl) * (F / 64) + 2 * c) * kF8Rec + lane; };
+  auto w2f8_lane = [&](const WPtrs& W, int c, int h = 0) {  // column pass h of chunk c
+    return W.w2f8 + ((size_t)(NT2 * wl + NTP * h) * (F / 64) + 2 * c) * kF8Rec + lane;
+  };
   auto fill1 = [&](const WPtrs& W, int ft) {  // start the W1 stream of hidden tile ft
     if constexpr (NP == 8) {
       ring_fill_f8<kPF1, 1>(r1, w1f8_lane(W, ft), 0);
@@ -262,11 +268,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   };
   auto fill2 = [&](const WPtrs& W, int c) {  // start the W2 stream of chunk c
     if constexpr (NP == 8) {
-      ring_fill_f8<kPF2, NT2>(r2, w2f8_lane(W, c), w2f8_nt);
+      ring_fill_f8<kPF2, NTP>(r2, w2f8_lane(W, c), w2f8_nt);
 #pragma unroll
-      for (int g = 0; g < kNW2; ++g) f8_group_load<NT2>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
+      for (int g = 0; g < kNW2; ++g) f8_group_load<NTP>(wg2[g], w2f8_lane(W, c) + (size_t)g * kF8Rec, w2f8_nt);
     } else {
-      ring_fill<RNP, kPF2, NT2>(r2, W.w2p + ((size_t)(NT2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
+      ring_fill<RNP, kPF2, NTP>(r2, W.w2p + ((size_t)(NT2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane, w2_nt_stride,
                              min(kFC / 16, ks2_total - c * (kFC / 16)));
     }
   };
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   [[maybe_unused]] WRing<(QNP ? QNP : 1), kLPF, NW> rq;  // tail: first k-steps of this wave's Q weight tiles
   unsigned sink = 0;  // keeps the L2 warm-up loads alive
   const int nslots = nchunk + 2;
-  f32x16 acc2c[MT][NT2];  // consumers' [rows x D/4] output accumulators (unused by producers)
+  f32x16 acc2c[NH][MT][NTP];  // consumers' [rows x D/4] output accumulators (unused by producers)
   static_for<NS>([&](auto si_tag) {
     constexpr int si = decltype(si_tag)::value;  // NS is a template parameter and the loop is unrolled: as a runtime loop it makes
                                      // every ring and accumulator loop-carried (~250 spilled VGPRs in the hot loops)
@@ -419,8 +425,8 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
         if (s + 1 < nslots) slot(s + 1, accB, accA);
       }
     } else {
-      f32x16 (&acc2)[MT][NT2] = acc2c;
-      zero_acc(acc2);
+#pragma unroll
+      for (int h = 0; h < NH; ++h) zero_acc(acc2c[h]);
 #if EEC_WARM_SLOTS > 0
       unsigned warm[4] = {0u, 0u, 0u, 0u};
 #endif
@@ -451,13 +457,21 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           const uint4* w2_lane = W.w2p + ((size_t)(NT2 * wl) * ks2_total + c * (kFC / 16)) * 128 + lane;
           if constexpr (NP == 8) {  // the launcher guarantees F % 128 == 0 for this stream
             const char* h8_lane = lds_h + (cl & 1) * 2 * kHPlane + kHPlane + (lane & 31) * kH8Ld + hh * 32;
-            gemm_ring_f8<2, NT2, false, kPF2, NoSide, 0, kNW2, EEC_DROP2, MT>(acc2, h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
+            if constexpr (NH == 1) {
+              gemm_ring_f8<2, NTP, false, kPF2, NoSide, 0, kNW2, EEC_DROP2, MT>(acc2c[0], h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c), w2f8_nt, r2, wg2);
+            } else {
+#pragma unroll
+              for (int h = 0; h < NH; ++h) {
+                const uint4* next = h + 1 < NH ? w2f8_lane(W, c, h + 1) : (cl + 1 < nchunk ? w2f8_lane(W, phys(cl + 1), 0) : nullptr);
+                gemm_ring_f8<2, NTP, false, kPF2, NoSide, 0, kNW2, EEC_DROP2, MT, true>(acc2c[h], h_lane, kHLd, h8_lane, kH8Ld, w2f8_lane(W, c, h), w2f8_nt, r2, wg2, NoSide(), next);
+              }
+            }
           } else if (ks2 == kFC / 16) {
-            gemm_ring<RNP, kFC / 16, NT2, false, kPF2, NoSide, 0, MT>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+            gemm_ring<RNP, kFC / 16, NTP, false, kPF2, NoSide, 0, MT>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
           } else {
-            gemm_plain<RNP, NT2, false, MT>(acc2, h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+            gemm_plain<RNP, NTP, false, MT>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
           }
-          if (cl + 1 < nchunk) fill2(W, phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
+          if (NH == 1 && cl + 1 < nchunk) fill2(W, phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
         }
         TL_STAMP();  // consumer: slot work done
         __syncthreads();
@@ -483,7 +497,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // the consumers hold the [64, 256] result: stage it through the fp32 tile (the last barrier of the
     // loops guarantees that nobody still reads the H buffers it aliases)
     TL_STAMP();  // residual loads issued
-    if constexpr (!producer) acc_to_etile<MT, NT2>(lds_e, G::kELd, acc2c, (w_e & 3) * 32 * NT2, EEC_STAGE_FIELD(si, b2), lane_e);
+    if constexpr (!producer) {
+#pragma unroll
+      for (int h = 0; h < NH; ++h)
+        acc_to_etile<MT, NTP>(lds_e, G::kELd, acc2c[h], (w_e & 3) * 32 * NT2 + h * 32 * NTP, EEC_STAGE_FIELD(si, b2), lane_e);
+    }
     TL_STAMP();  // exchange tile written
     // the next phase's weight streams start only now, when the accumulators are dead (issued earlier, their
     // registers push the allocator into spilling, and scratch reloads queue behind these cold loads); the
@@ -513,10 +531,15 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   if ((sink ^ sink_front) == 0x9e3779b9u && M == -7) x[0] = 0.f;  // never true: the warm-up loads must not be optimised away
   TL_STAMP();  // last: epilogue done
   };
+#if defined(EEC_ONLY_ROLE)  // register-budget diagnostics: compile one role only (the kernel is then wrong, never run it)
+  (void)is_producer;
+  run(BoolTag<EEC_ONLY_ROLE != 0>{});
+#else
   if (is_producer)
     run(BoolTag<true>{});
   else
     run(BoolTag<false>{});
+#endif
 }
 
 #if defined(EEC_TIMELINE) && (!defined(EEC_FFN_D) || EEC_FFN_D == 256)
@@ -559,13 +582,21 @@ hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_f
   if (a.nstage < 1 || a.nstage > 2) return hipErrorInvalidValue;
   for (int i = 0; i < a.nstage; ++i)
     if (np == 8 && (a.F % kFC != 0 || !a.st[i].w1f8 || !a.st[i].w2f8)) np = 3;  // the f8 stream needs whole 128-wide chunks
+#ifndef EEC_CHAIN_MINIMAL
   if (relu) {
     if (front || tail || a.nstage != 1) return hipErrorInvalidValue;
     if (np == 8) return launch_chain_t<D, 8, 1, 0, 0, 1>(a, st);
     if (np == 3) return launch_chain_t<D, 3, 1, 0, 0, 1>(a, st);
     return launch_chain_t<D, 1, 1, 0, 0, 1>(a, st);
   }
+#endif
   const int f = front ? np_front : 0, q = tail ? np_tail : 0;
+#ifdef EEC_CHAIN_MINIMAL  // tuning builds: only the three launches of the default (f16f8) production plan
+  if (np == 8 && f == 0 && q == 3 && a.nstage == 1) return launch_chain_t<D, 8, 0, 0, 3, 1>(a, st);
+  if (np == 8 && f == 3 && q == 3 && a.nstage == 2) return launch_chain_t<D, 8, 0, 3, 3, 2>(a, st);
+  if (np == 8 && f == 3 && q == 0 && a.nstage == 1) return launch_chain_t<D, 8, 0, 3, 0, 1>(a, st);
+  return hipErrorInvalidValue;
+#else
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
   if (np == NP_ && f == F_ && q == Q_)                                                                   \
     return a.nstage == 2 ? launch_chain_t<D, NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<D, NP_, 0, F_, Q_, 1>(a, st);
@@ -578,6 +609,7 @@ hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_f
 #endif
 #undef EEC_CHAIN_CASE
   return hipErrorInvalidValue;
+#endif
 }
 
 #if EEC_FFN_D == 256

@@ -1,19 +1,22 @@
 #!/bin/bash
 # build_variant.sh <name> "<defines>" <file.hip> [file.hip ...]
 # Recompiles the named sources with extra -D flags and links libeec_<name>.so against the base objects
-# (tuning experiments; bench them with tools/variants.sh <name> ...).
+# (tuning experiments; bench them with tools/ab_variants.py).  ffn.hip is built with -DEEC_CHAIN_MINIMAL (only the three
+# chain-kernel variants of the default f16f8 production plan, d_model 256) unless EEC_FULL=1.
 set -e
 name=$1; defs=$2; shift 2
 cd "$(dirname "$0")/../early_exit_transformer_amd/csrc"
-make -s -j6
+[ -f build/capi.o ] || make -s -j6
 objs=""
 for s in capi ffn linear attention conv stem ctc pack; do
   if [[ " $* " == *" $s.hip "* ]]; then
-    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed $defs -c $s.hip -o build/${s}_$name.o
+    extra=""
+    if [ "$s" = ffn ] && [ "${EEC_FULL:-0}" != 1 ]; then extra="-DEEC_CHAIN_MINIMAL"; fi
+    /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-pass-failed $defs $extra -c $s.hip -o build/${s}_$name.o
     objs="$objs build/${s}_$name.o"
   else
     objs="$objs build/$s.o"
   fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs -o libeec_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs build/ffn512.o -o libeec_$name.so
 echo built libeec_$name.so
