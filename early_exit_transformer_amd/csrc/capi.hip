@@ -739,7 +739,41 @@ int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* targe
   if (blank < 0 || blank >= V) return fail(EEC_ERR_BAD_ARG, "blank must be a label in [0, V)");
   if (2 * S + 1 > 512) return fail(EEC_ERR_UNSUPPORTED, "target length above 255");
   EEC_HIP(launch_ctc_loss(logp, (const long long*)targets, (const long long*)target_len, E, B, Tq, V, S, blank, nll_scratch,
-                          loss_per_exit, (hipStream_t)stream));
+                          loss_per_exit, nullptr, (hipStream_t)stream));
+  return 0;
+}
+
+size_t eec_ctc_backward_workspace_bytes(int E, int B, int Tq, int S) {
+  if (E <= 0 || B <= 0 || Tq <= 0 || S <= 0) return 0;
+  return ctc_store_floats(E, B, Tq, S) * sizeof(float);
+}
+
+int eec_ctc_loss_forward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                         int blank, float* nll, float* loss_per_exit, void* bwd_workspace, void* stream) {
+  if (!logp || !targets || !target_len || !nll || !loss_per_exit || !bwd_workspace) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (E <= 0 || B <= 0 || Tq <= 0 || V <= 0 || S <= 0) return fail(EEC_ERR_BAD_ARG, "bad size");
+  if (blank < 0 || blank >= V) return fail(EEC_ERR_BAD_ARG, "blank must be a label in [0, V)");
+  if (2 * S + 1 > 512) return fail(EEC_ERR_UNSUPPORTED, "target length above 255");
+  EEC_HIP(launch_ctc_loss(logp, (const long long*)targets, (const long long*)target_len, E, B, Tq, V, S, blank, nll,
+                          loss_per_exit, (float*)bwd_workspace, (hipStream_t)stream));
+  return 0;
+}
+
+int eec_ctc_loss_backward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                          int blank, const float* nll, void* bwd_workspace, const float* grad_loss, float* dlogp, void* stream) {
+  if (!logp || !targets || !target_len || !nll || !bwd_workspace || !grad_loss || !dlogp) return fail(EEC_ERR_BAD_ARG, "null argument");
+  if (E <= 0 || B <= 0 || Tq <= 0 || V <= 0 || S <= 0) return fail(EEC_ERR_BAD_ARG, "bad size");
+  if (V > 256 || V % 4) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 4, <= 256");
+  if (2 * S + 1 > 512) return fail(EEC_ERR_UNSUPPORTED, "target length above 255");
+  EEC_HIP(launch_ctc_backward(logp, (const long long*)targets, (const long long*)target_len, E, B, Tq, V, S, blank, nll,
+                              (float*)bwd_workspace, grad_loss, dlogp, (hipStream_t)stream));
+  return 0;
+}
+
+int eec_logsoftmax_backward(const float* logp, const float* grad_logp, int M, int V, float* grad_logits, void* stream) {
+  if (!logp || !grad_logp || !grad_logits || M <= 0 || V <= 0) return fail(EEC_ERR_BAD_ARG, "bad argument");
+  if (V > 256 || V % 4) return fail(EEC_ERR_UNSUPPORTED, "vocab must be a multiple of 4, <= 256");
+  EEC_HIP(launch_logsoftmax_backward(logp, grad_logp, M, V, grad_logits, (hipStream_t)stream));
   return 0;
 }
 

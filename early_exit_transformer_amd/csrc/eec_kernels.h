@@ -151,8 +151,15 @@ hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_
 hipError_t launch_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int* tokens, int* counts,
                              hipStream_t st);
 
-// batched CTC forward: per-lattice negative log-likelihoods nll[E*B] and per-exit batch-mean losses out[E]
+// batched CTC forward: per-lattice negative log-likelihoods nll[E*B] and per-exit batch-mean losses out[E];
+// astore (optional, ctc_store_floats() floats): the scaled alphas of every step, for launch_ctc_backward
 hipError_t launch_ctc_loss(const float* logp, const long long* targets, const long long* target_len, int E, int B, int Tq,
-                           int V, int S, int blank, float* nll, float* out, hipStream_t st);
+                           int V, int S, int blank, float* nll, float* out, float* astore, hipStream_t st);
+size_t ctc_store_floats(int E, int B, int Tq, int S);
+// dlogp[E][B][Tq][V] = d( sum_e grad_loss[e] * loss_e ) / d logp  (astore is consumed: overwritten with state posteriors)
+hipError_t launch_ctc_backward(const float* logp, const long long* targets, const long long* target_len, int E, int B, int Tq,
+                               int V, int S, int blank, const float* nll, float* astore, const float* grad_loss, float* dlogp,
+                               hipStream_t st);
+hipError_t launch_logsoftmax_backward(const float* logp, const float* g, int M, int V, float* dlogits, hipStream_t st);
 
 }  // namespace eec

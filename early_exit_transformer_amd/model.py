@@ -178,7 +178,7 @@ class _HipEncoderMixin:
         if not src.is_cuda:
             raise RuntimeError("the MI355X encoder runs on a HIP device only; move the model and inputs to "
                                "'cuda' (there is no CPU fallback -- the CPU reference lives in oracle/).")
-        if self.training and torch.is_grad_enabled():
+        if self.training and torch.is_grad_enabled() and not getattr(self, "_frozen_encoder_pass", False):
             raise NotImplementedError("training (autograd through the HIP encoder, batch-stat BatchNorm, dropout) "
                                       "is not built yet; call under model.eval() / torch.no_grad()")
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
@@ -244,7 +244,28 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
                        features_length, dec_voc_size, max_len)
 
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        if self.training and torch.is_grad_enabled():
+            return self._forward_heads_trainable(src, lengths)
         return self._run_encoder(src, lengths)[0]
+
+    def _forward_heads_trainable(self, src: Tensor, lengths: Tensor) -> Tensor:
+        """First slice of the training path (train.py:53-70): the exit heads ``linears.*`` are trainable on a FROZEN
+        encoder.  The encoder stack runs on the HIP path without autograd, in eval semantics (running BatchNorm
+        statistics, no dropout) whatever ``self.training`` says; the heads are an autograd function over its taps, so
+        ``exit_ctc_losses(model(src, lengths), ...).sum().backward()`` fills ``linears.*.grad``.  A trainable parameter
+        anywhere else still raises: the encoder's own backward is not built."""
+        trainable = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("linears.")]
+        if trainable:
+            raise NotImplementedError("only the exit heads (linears.*) can be trained yet: freeze the encoder "
+                                      f"(requires_grad_(False)); trainable now: {trainable[:3]}{' ...' if len(trainable) > 3 else ''}")
+        self._frozen_encoder_pass = True
+        try:
+            with torch.no_grad():
+                taps = self._run_encoder(src, lengths, want_out=False, want_taps=True, n_groups=self._cfg.n_exits)[1]
+        finally:
+            self._frozen_encoder_pass = False
+        wb = [l.weight for l in self.linears] + [l.bias for l in self.linears]
+        return _ExitHeadsFn.apply(self, taps, *wb)
 
     def forward_exits(self, src: Tensor, lengths: Tensor, n_exits: int) -> Tensor:
         """Early exit (extension; the reference's forward always runs every group): log-probs of the first
@@ -486,17 +507,66 @@ def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
     return tokens, counts
 
 
-def exit_ctc_losses(enc_out: Tensor, targets: Tensor, target_len: Tensor, blank: int = 0) -> Tensor:
-    """Per-exit CTC losses [E] of an encoder output [E, B, T', V] in ONE launch: what train.py:53-65 computes with
-    E separate nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) calls and input length T' for every
-    utterance.  ``.sum()`` is the reference's training loss.  Forward only (no autograd)."""
+def _ctc_prepare(enc_out: Tensor, targets: Tensor, target_len: Tensor):
     if not enc_out.is_cuda:
         raise RuntimeError("exit_ctc_losses runs on a HIP device only")
     enc_out = enc_out.contiguous().float()
-    E, B, Tq, V = enc_out.shape
     dev = enc_out.device
     tg = targets.to(device=dev, dtype=torch.int64).contiguous()
     tl = target_len.to(device=dev, dtype=torch.int64).contiguous()
+    return enc_out, tg, tl
+
+
+class _ExitCtcLossFn(torch.autograd.Function):
+    """Per-exit CTC losses [E] with their gradient with respect to the log-probs (eec_ctc_loss_forward / _backward):
+    what autograd computes through the reference's loop of E nn.CTCLoss calls (train.py:60-68)."""
+
+    @staticmethod
+    def forward(ctx, enc_out, tg, tl, blank):
+        E, B, Tq, V = enc_out.shape
+        dev = enc_out.device
+        lib = capi.load()
+        nll = torch.empty((E * B,), dtype=torch.float32, device=dev)
+        out = torch.empty((E,), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.eec_ctc_backward_workspace_bytes(E, B, Tq, tg.size(1)) + 256,), dtype=torch.uint8, device=dev)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            capi.check(lib.eec_ctc_loss_forward(enc_out.data_ptr(), tg.data_ptr(), tl.data_ptr(), E, B, Tq, V, tg.size(1), blank,
+                                                nll.data_ptr(), out.data_ptr(), ws_ptr, C.c_void_p(stream)), "eec_ctc_loss_forward")
+        ctx.save_for_backward(enc_out, tg, tl, nll, ws)
+        ctx.blank = blank
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        enc_out, tg, tl, nll, ws = ctx.saved_tensors
+        if getattr(ctx, "used", False):
+            raise RuntimeError("exit_ctc_losses: backward through the same forward twice (its workspace is consumed)")
+        ctx.used = True
+        E, B, Tq, V = enc_out.shape
+        dev = enc_out.device
+        g = grad_out.to(device=dev, dtype=torch.float32).contiguous()
+        dlogp = torch.empty_like(enc_out)
+        ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            capi.check(capi.load().eec_ctc_loss_backward(enc_out.data_ptr(), tg.data_ptr(), tl.data_ptr(), E, B, Tq, V, tg.size(1),
+                                                         ctx.blank, nll.data_ptr(), ws_ptr, g.data_ptr(), dlogp.data_ptr(),
+                                                         C.c_void_p(stream)), "eec_ctc_loss_backward")
+        return dlogp, None, None, None
+
+
+def exit_ctc_losses(enc_out: Tensor, targets: Tensor, target_len: Tensor, blank: int = 0) -> Tensor:
+    """Per-exit CTC losses [E] of an encoder output [E, B, T', V] in ONE launch: what train.py:53-65 computes with
+    E separate nn.CTCLoss(blank=0, reduction='mean', zero_infinity=True) calls and input length T' for every
+    utterance.  ``.sum()`` is the reference's training loss.  Differentiable with respect to ``enc_out`` (HIP backward:
+    beta recursion + dense gradient, the values torch autograd returns for the reference's loop)."""
+    enc_out, tg, tl = _ctc_prepare(enc_out, targets, target_len)
+    E, B, Tq, V = enc_out.shape
+    if torch.is_grad_enabled() and enc_out.requires_grad:
+        return _ExitCtcLossFn.apply(enc_out, tg, tl, blank)
+    dev = enc_out.device
     nll = torch.empty((E * B,), dtype=torch.float32, device=dev)
     out = torch.empty((E,), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
@@ -504,6 +574,47 @@ def exit_ctc_losses(enc_out: Tensor, targets: Tensor, target_len: Tensor, blank:
         capi.check(capi.load().eec_ctc_loss(enc_out.data_ptr(), tg.data_ptr(), tl.data_ptr(), E, B, Tq, V, tg.size(1), blank,
                                             nll.data_ptr(), out.data_ptr(), C.c_void_p(stream)), "eec_ctc_loss")
     return out
+
+
+class _ExitHeadsFn(torch.autograd.Function):
+    """All exit heads on given encoder taps: log_softmax(taps[e] . W_e^T + b_e) (early_exit.py:629-631), forward through
+    the HIP head kernel, backward = HIP log-softmax backward + the two plain GEMMs of a Linear's backward."""
+
+    @staticmethod
+    def forward(ctx, model, taps, *wb):
+        E, B, Tq, D = taps.shape
+        V = model._cfg.vocab
+        dev = taps.device
+        lib = capi.load()
+        out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            for e in range(E):
+                capi.check(lib.eec_encoder_head_forward(model._enc, e, taps[e].data_ptr(), B * Tq, out[e].data_ptr(),
+                                                        capi.PRECISIONS[model.precision], C.c_void_p(stream)), "eec_encoder_head_forward")
+        ctx.save_for_backward(taps, out, *wb[:E])
+        ctx.need_taps = taps.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        taps, out = ctx.saved_tensors[:2]
+        ws = ctx.saved_tensors[2:]
+        E, B, Tq, D = taps.shape
+        V = out.size(-1)
+        dev = taps.device
+        g = g.contiguous().float()
+        dlogits = torch.empty_like(out)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            capi.check(capi.load().eec_logsoftmax_backward(out.data_ptr(), g.data_ptr(), E * B * Tq, V, dlogits.data_ptr(),
+                                                           C.c_void_p(stream)), "eec_logsoftmax_backward")
+        dl = dlogits.reshape(E, B * Tq, V)
+        x = taps.reshape(E, B * Tq, D)
+        dW = [dl[e].t() @ x[e] for e in range(E)]  # plain fp32 library GEMMs (rocBLAS through torch)
+        db = [dl[e].sum(0) for e in range(E)]
+        dtaps = torch.stack([dl[e] @ ws[e] for e in range(E)]).reshape(taps.shape) if ctx.need_taps else None
+        return (None, dtaps, *dW, *db)
 
 
 class full_conformer(_HipEncoderMixin, nn.Module):

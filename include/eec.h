@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 7
+#define EEC_ABI_VERSION 8
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -201,6 +201,24 @@ int eec_greedy_ctc(const float* logp, int n_seq, int Tq, int V, int blank, int32
  * propagate as NaN; only +inf (an infeasible alignment) is zeroed, as zero_infinity=True does. */
 int eec_ctc_loss(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
                  int blank, float* nll_scratch, float* loss_per_exit, void* stream);
+
+/* Backward of the per-exit loss loop (train.py:60-68: loss.backward() through E nn.CTCLoss calls), first slice of the
+ * training path: gradient with respect to the encoder's log-prob output.
+ *   eec_ctc_loss_forward: as eec_ctc_loss, and additionally keeps every step's forward variables in `bwd_workspace`
+ *       (eec_ctc_backward_workspace_bytes(E, B, T', S) bytes, 256-byte aligned device memory; nll [E*B] is an output
+ *       the backward needs again).
+ *   eec_ctc_loss_backward: dlogp [E, B, T', V] = d( sum_e grad_loss[e] * loss_e ) / d logp, what torch autograd returns
+ *       for the same loop (for each lattice grad * (exp(logp) - state posteriors), zero for an infeasible lattice);
+ *       consumes bwd_workspace (call once per forward).
+ *   eec_logsoftmax_backward: grad_logits = grad_logp - exp(logp) * sum_c grad_logp  (rows of V <= 256 entries): the
+ *       log-softmax half of the exit heads' backward (early_exit.py:629-631); the two plain GEMMs of the Linear's
+ *       backward (dW = grad_logits^T . x, dx = grad_logits . W) are library GEMMs on the caller's side. */
+size_t eec_ctc_backward_workspace_bytes(int E, int B, int Tq, int S);
+int eec_ctc_loss_forward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                         int blank, float* nll, float* loss_per_exit, void* bwd_workspace, void* stream);
+int eec_ctc_loss_backward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
+                          int blank, const float* nll, void* bwd_workspace, const float* grad_loss, float* dlogp, void* stream);
+int eec_logsoftmax_backward(const float* logp, const float* grad_logp, int M, int V, float* grad_logits, void* stream);
 
 #ifdef __cplusplus
 }
