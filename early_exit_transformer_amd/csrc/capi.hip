@@ -37,9 +37,9 @@ struct PackedLayer {
   float *ffn1_ln_w, *ffn1_ln_b, *ffn1_b1, *ffn1_b2;
   uint4 *ffn1_w1p, *ffn1_w2p, *ffn1_w1f8, *ffn1_w2f8;
   float *attn_ln_w, *attn_ln_b, *attn_in_b, *attn_out_b;
-  uint4 *attn_in_p, *attn_out_p;
+  uint4 *attn_in_p, *attn_out_p, *attn_in_f8, *attn_out_f8;
   float *conv_ln_w, *conv_ln_b, *conv_pw1_b, *conv_pw2_b, *dw_wfold, *dw_bfold;
-  uint4 *conv_pw1_p, *conv_pw2_p;
+  uint4 *conv_pw1_p, *conv_pw2_p, *conv_pw1_f8, *conv_pw2_f8;
   float *ffn2_ln_w, *ffn2_ln_b, *ffn2_b1, *ffn2_b2;
   uint4 *ffn2_w1p, *ffn2_w2p, *ffn2_w1f8, *ffn2_w2f8;
   float *final_ln_w, *final_ln_b;
@@ -82,7 +82,7 @@ struct eec_encoder {
   std::vector<PackedLayer> layers;
   uint4 *sub_w1p, *sub_w2p;
   float *sub_b1, *sub_b2, *pe;
-  std::vector<uint4*> head_p;
+  std::vector<uint4*> head_p, head_f8;
   std::vector<float*> head_b;
 
   void carve() {
@@ -103,6 +103,8 @@ struct eec_encoder {
       L.attn_out_b = arena.take<float>(D);
       L.attn_in_p = arena.take<uint4>(frag_u4(3 * D, D));
       L.attn_out_p = arena.take<uint4>(frag_u4(D, D));
+      L.attn_in_f8 = arena.take<uint4>(f8_u4(3 * D, D));
+      L.attn_out_f8 = arena.take<uint4>(f8_u4(D, D));
       L.conv_ln_w = arena.take<float>(D);
       L.conv_ln_b = arena.take<float>(D);
       L.conv_pw1_b = arena.take<float>(2 * D);
@@ -111,6 +113,8 @@ struct eec_encoder {
       L.dw_bfold = arena.take<float>(D);
       L.conv_pw1_p = arena.take<uint4>(frag_u4(2 * D, D));
       L.conv_pw2_p = arena.take<uint4>(frag_u4(D, D));
+      L.conv_pw1_f8 = arena.take<uint4>(f8_u4(2 * D, D));
+      L.conv_pw2_f8 = arena.take<uint4>(f8_u4(D, D));
       L.ffn2_ln_w = arena.take<float>(D);
       L.ffn2_ln_b = arena.take<float>(D);
       L.ffn2_b1 = arena.take<float>(F);
@@ -128,9 +132,11 @@ struct eec_encoder {
     sub_b2 = arena.take<float>(D);
     pe = arena.take<float>((size_t)cfg.max_len * D);
     head_p.assign(cfg.n_exits, nullptr);
+    head_f8.assign(cfg.n_exits, nullptr);
     head_b.assign(cfg.n_exits, nullptr);
     for (int e = 0; e < cfg.n_exits; ++e) {
       head_p[e] = arena.take<uint4>(frag_u4(cfg.vocab, D));
+      head_f8[e] = arena.take<uint4>(f8_u4(cfg.vocab, D));
       head_b[e] = arena.take<float>(cfg.vocab);
     }
     arena.off = align_up(arena.off);
@@ -230,7 +236,7 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
   const eec_config& c = enc->cfg;
   const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
   auto qkv_args = [&](const PackedLayer& L) {
-    return QkvArgs{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo};
+    return QkvArgs{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo, L.attn_in_f8};
   };
   auto stage1 = [&](const PackedLayer& L) {
     return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
@@ -247,14 +253,14 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     const PackedLayer& L = enc->layers[li];
     const bool last = li + 1 == l1;
     AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
-    TIMED(KC_ATTN, launch_attention(at, np.att, st));
-    ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b};
-    GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g};
+    TIMED(KC_ATTN, launch_attention(at, np.att == 1 ? 1 : 3, st));
+    ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
+    GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g, L.conv_pw1_f8};
     TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
     ChainArgs ca{};
     ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = last ? 1 : 2;
     ca.dw = DwArgs{b.g, B, Tq, L.dw_wfold, L.dw_bfold, b.p_hi, b.p_lo};
-    ca.pw2 = ProjResArgs{b.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
+    ca.pw2 = ProjResArgs{b.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b, L.conv_pw2_f8};
     ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,
                         L.ffn2_w1f8, L.ffn2_w2f8, 0.5f, tap_of(li)};
     if (!last) {
@@ -346,12 +352,16 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     EEC_HIP(cp(L.attn_out_b, s.attn_out_b, D));
     EEC_HIP(launch_pack_frags(s.attn_in_w, 3 * D, D, L.attn_in_p, 1.0f, st));
     EEC_HIP(launch_pack_frags(s.attn_out_w, D, D, L.attn_out_p, 1.0f, st));
+    EEC_HIP(launch_pack_frags_f8(s.attn_in_w, 3 * D, D, L.attn_in_f8, 1.0f, st));
+    EEC_HIP(launch_pack_frags_f8(s.attn_out_w, D, D, L.attn_out_f8, 1.0f, st));
     EEC_HIP(cp(L.conv_ln_w, s.conv_ln_w, D));
     EEC_HIP(cp(L.conv_ln_b, s.conv_ln_b, D));
     EEC_HIP(cp(L.conv_pw1_b, s.conv_pw1_b, 2 * D));
     EEC_HIP(cp(L.conv_pw2_b, s.conv_pw2_b, D));
     EEC_HIP(launch_pack_frags(s.conv_pw1_w, 2 * D, D, L.conv_pw1_p, 1.0f, st));
     EEC_HIP(launch_pack_frags(s.conv_pw2_w, D, D, L.conv_pw2_p, 1.0f, st));
+    EEC_HIP(launch_pack_frags_f8(s.conv_pw1_w, 2 * D, D, L.conv_pw1_f8, 1.0f, st));
+    EEC_HIP(launch_pack_frags_f8(s.conv_pw2_w, D, D, L.conv_pw2_f8, 1.0f, st));
     EEC_HIP(launch_fold_dw(s.conv_dw_w, s.conv_dw_b, s.conv_bn_w, s.conv_bn_b, s.conv_bn_rm, s.conv_bn_rv,
                            c.dw_kernel, D, L.dw_wfold, L.dw_bfold, st));
     EEC_HIP(cp(L.ffn2_ln_w, s.ffn2_ln_w, D));
@@ -386,6 +396,7 @@ int eec_encoder_pack(eec_encoder* enc, const eec_params* p, void* stream) {
     for (int e = 0; e < c.n_exits; ++e) {
       if (!p->head_w[e] || !p->head_b[e]) return fail(EEC_ERR_BAD_ARG, "null head parameter");
       EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
+      EEC_HIP(launch_pack_frags_f8(p->head_w[e], c.vocab, D, enc->head_f8[e], 1.0f, st));
       EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
     }
   enc->packed = true;
@@ -451,6 +462,7 @@ int eec_encoder_pack_legacy(eec_encoder* enc, const eec_legacy_params* p, void* 
     for (int e = 0; e < c.n_exits; ++e) {
       if (!p->head_w[e] || !p->head_b[e]) return fail(EEC_ERR_BAD_ARG, "null head parameter");
       EEC_HIP(launch_pack_frags(p->head_w[e], c.vocab, D, enc->head_p[e], 1.0f, st));
+      EEC_HIP(launch_pack_frags_f8(p->head_w[e], c.vocab, D, enc->head_f8[e], 1.0f, st));
       EEC_HIP(cp(enc->head_b[e], p->head_b[e], c.vocab));
     }
   enc->packed = true;
@@ -484,8 +496,14 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   hipStream_t st = (hipStream_t)stream;
   const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
-  // operand format per GEMM group of the production plan (all np_o; a diagnostic build can override them one by one)
-  int np_qkv = np_o, np_att = np_o, np_glu = np_o, np_front = np_o, np_head = np_o;
+  // f16f8 (default): besides the feed-forward, out_proj + pointwise-1 and pointwise-2 run on the f8 stream
+  // (fp16 + two fp8 correction products); in_proj (its error is amplified by the softmax) and the exit heads (their
+  // error is the logit error) keep the exact 3-pass split.  Measured on the default model, 3 weight / input seeds
+  // (profiles/r02_np_budget.txt): max |dlogp| 2.5e-4; with in_proj on f8 as well 3.6e-4, heads too 4.0e-4
+  // (d_model 512 keeps the fragment formats there: its f8 projection kernels do not fit the register file yet)
+  const int np_p = (precision == EEC_PREC_F16F8 && c.arch == EEC_ARCH_CONFORMER && c.d_model == 256 && c.d_ff % 128 == 0) ? 8 : np_o;
+  // operand format per GEMM group of the production plan (a diagnostic build can override them one by one)
+  int np_qkv = np_o, np_att = np_o, np_glu = np_p, np_front = np_p, np_head = np_o;
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * c.d_model : nullptr;  // V keeps its fp16 residual in the split modes
 #ifdef EEC_NP_EXPERIMENT
   if (const char* ov = getenv("EEC_NP_OVERRIDE")) {  // e.g. "qkv=1,glu=1": error-budget experiments (tools/np_budget.py)
@@ -571,9 +589,9 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
         const int li = (e + 1) * c.layers_per_exit - 1;
         const float* rows = li + 1 == n_layers ? ws.x : tap_of(li);
         if (batch_heads) {
-          hb.x[e] = rows, hb.wp[e] = enc->head_p[e], hb.bias[e] = enc->head_b[e];
+          hb.x[e] = rows, hb.wp[e] = enc->head_p[e], hb.wf8[e] = enc->head_f8[e], hb.bias[e] = enc->head_b[e];
         } else {
-          HeadArgs h{rows, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+          HeadArgs h{rows, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab, enc->head_f8[e]};
           TIMED(KC_HEAD, launch_head(h, np_head, st));
         }
       }
@@ -593,27 +611,27 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       ++step;
       if (done()) return finish_dbg();
       {
-        QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo};
+        QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo, L.attn_in_f8};
         TIMED(KC_QKV, launch_qkv(a, np_o, st));
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
-        ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b};
-        GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g};
+        ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
+        GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g, L.conv_pw1_f8};
         // out-proj + residual and the conv module's LN -> pointwise-1 -> GLU share one launch
         // (the sub-step hook stops between them, so it falls back to the two separate kernels)
         const bool split_here = stop_after >= 0 && step + 1 > stop_after;
         if (split_here) {
           TIMED(KC_PROJ, launch_proj_residual(pr, np_o, st));
         } else {
-          TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_o, st));
+          TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np_p, st));
         }
         ++step;
         if (done()) return finish_dbg();
       }
       {
         DwArgs da{ws.g, B, Tq, L.dw_wfold, L.dw_bfold, ws.p_hi, ws.p_lo};
-        ProjResArgs pr{ws.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b};
-        TIMED(KC_DW_PW2, launch_dw_pw2(da, pr, np_o, st));
+        ProjResArgs pr{ws.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b, L.conv_pw2_f8};
+        TIMED(KC_DW_PW2, launch_dw_pw2(da, pr, np_p, st));
       }
       ++step;
       if (done()) return finish_dbg();
@@ -626,7 +644,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (done()) return finish_dbg();
     }
     if (out) {
-      HeadArgs h{ws.x, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab};
+      HeadArgs h{ws.x, M, c.vocab, D, enc->head_p[e], enc->head_b[e], out + (size_t)e * M * c.vocab, enc->head_f8[e]};
       TIMED(KC_HEAD, launch_head(h, np_o, st));
     }
     if (taps_opt)
@@ -701,7 +719,8 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * D : nullptr;
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   const LayerBufs bufs{x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, key_len};
-  const LayerFormats nps{np_ffn, np_o, np_o, np_o, np_o};
+  const int np_p = (precision == EEC_PREC_F16F8 && c.d_model == 256 && c.d_ff % 128 == 0) ? 8 : np_o;
+  const LayerFormats nps{np_ffn, np_p, np_o, np_o, np_p};  // {ffn, front, qkv, att, glu}
   const int l0 = group * c.layers_per_exit;
   return run_layer_plan(enc, l0, l0 + c.layers_per_exit, bufs, B, Tq, nps, [](int) -> float* { return nullptr; }, st);
 }
@@ -726,7 +745,7 @@ int eec_encoder_head_forward(eec_encoder* enc, int exit, const float* x, int M, 
   if (int rc = check_device(enc)) return rc;
   if (exit < 0 || exit >= enc->cfg.n_exits || M <= 0) return fail(EEC_ERR_BAD_ARG, "exit / M out of range");
   if (precision < EEC_PREC_F16X3 || precision > EEC_PREC_F16F8) return fail(EEC_ERR_BAD_ARG, "unknown precision");
-  HeadArgs h{x, M, enc->cfg.vocab, enc->cfg.d_model, enc->head_p[exit], enc->head_b[exit], out};
+  HeadArgs h{x, M, enc->cfg.vocab, enc->cfg.d_model, enc->head_p[exit], enc->head_b[exit], out, enc->head_f8[exit]};
   hipStream_t st = (hipStream_t)stream;
   TIMED(KC_HEAD, launch_head(h, precision == EEC_PREC_F16 ? 1 : 3, st));
   return 0;

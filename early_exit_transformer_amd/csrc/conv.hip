@@ -26,8 +26,8 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
   const int row0 = blockIdx.x * G::kRows;
   const int M = a.M;
   EEC_TL_STAMP(dw, 0);
-  WRing<NP, kDPF, G::kNW> r;
-  ring_fill<NP, kDPF, G::kNW>(r, wfrag_lane<G::kKS>(a.wp, G::kNW * w), (size_t)G::kKS * 128, G::kKS);
+  ProjStream<NP, kDPF, G::kNW> r;
+  proj_fill<D, NP, kDPF, G::kNW>(r, WMat{a.wp, a.wf8}, G::kNW * w);
   dw_front<D, NP>(smem, d, M, row0);
   EEC_TL_STAMP(dw, 3);
   __syncthreads();
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
 
 template <int D>
 static hipError_t launch_dw_pw2_d(const DwArgs& d, const ProjResArgs& a, int np, hipStream_t st) {
-  auto k = np == 3 ? dw_pw2_kernel<D, 3> : dw_pw2_kernel<D, 1>;
+  auto k = np == 8 ? dw_pw2_kernel<D, 8> : np == 3 ? dw_pw2_kernel<D, 3> : dw_pw2_kernel<D, 1>;
   if (hipError_t e = ensure_max_lds((const void*)k, DwGeo<D>::kLds); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(512), DwGeo<D>::kLds, st, d, a);
   return hipGetLastError();

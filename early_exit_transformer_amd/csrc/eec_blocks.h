@@ -42,19 +42,64 @@ __device__ __forceinline__ const uint4* wfrag_lane(const uint4* wp, int nt) {
   return wp + (size_t)nt * KS * 128 + lane_id();
 }
 
+// ---------------------------------------------------------------------------
+// One K = D product of a row tile against NT adjacent 32-wide column tiles of a packed weight matrix, swapped orientation
+// (lane = frame), activation planes in LDS in the NP format:
+//   NP = 1 / 3: fp16 hi (/ + lo) planes, weights as hi (/ lo) fragments (wp);
+//   NP = 8    : fp16 hi plane + e5m2 lo byte plane, weights as the f8 record stream (wf8): fp16 main product + two
+//               block-scaled fp8 correction products (eec_device.h, gemm_ring_f8) -- 2 pass-equivalents, 3 B / weight.
+// A ProjStream holds the weight registers in flight; proj_fill starts a tile set's stream (one product ahead of its use).
+constexpr int kProjNWB = 2;  // lo8 + scale group buffers of an f8 stream (rolling)
+template <int NP, int PF, int NT>
+struct ProjStream {
+  WRing<(NP == 8 ? 1 : NP), PF, NT> r;
+  WGroupF8<NT> wg[NP == 8 ? kProjNWB : 1];
+};
+struct WMat {  // the two packings of one weight matrix [N][D]
+  const uint4* wp;   // fragment planes (NP = 1, 3)
+  const uint4* wf8;  // f8 record stream (NP = 8)
+};
+template <int D, int NP, int PF, int NT>
+__device__ __forceinline__ void proj_fill(ProjStream<NP, PF, NT>& st, const WMat& w, int t0) {
+  constexpr int KS = D / 16, NG = D / 64;
+  if constexpr (NP == 8) {
+    const uint4* rec = w.wf8 + (size_t)t0 * NG * kF8Rec + lane_id();
+    ring_fill_f8<PF, NT>(st.r, rec, (size_t)NG * kF8Rec);
+#pragma unroll
+    for (int g = 0; g < kProjNWB; ++g) f8_group_load<NT>(st.wg[g], rec + (size_t)g * kF8Rec, (size_t)NG * kF8Rec);
+  } else {
+    ring_fill<NP, PF, NT>(st.r, wfrag_lane<KS>(w.wp, t0), (size_t)KS * 128, KS);
+  }
+}
+template <int D, int NP, int PF, int NT, int MT>
+__device__ __forceinline__ void proj_gemm(f32x16 (&acc)[MT][NT], const char* smem, ProjStream<NP, PF, NT>& st, const WMat& w, int t0,
+                                          int row_stride_mul = 1) {
+  using G = Geo<D>;
+  constexpr int KS = D / 16, NG = D / 64;
+  const int lane = lane_id(), hh = lane >> 5;
+  const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
+  if constexpr (NP == 8) {
+    const char* a8_lane = smem + G::kAPlane + (lane & 31) * G::kA8Ld + hh * 32;
+    const uint4* rec = w.wf8 + (size_t)t0 * NG * kF8Rec + lane;
+    gemm_ring_f8<NG, NT, true, PF, NoSide, 0, kProjNWB, 0, MT>(acc, a_lane, G::kALd, a8_lane, G::kA8Ld, rec, (size_t)NG * kF8Rec, st.r, st.wg);
+  } else {
+    gemm_ring<NP, KS, NT, true, PF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(w.wp, t0), (size_t)KS * 128, st.r);
+  }
+  (void)row_stride_mul;
+}
+
 // Q / K / V products of one row tile whose LayerNormed activation planes are in LDS (NP format), the
 // planes being complete and visible (caller has passed a workgroup barrier).  `rq` holds the first kLPF
 // k-steps of this wave's Q weight tiles (filled by the caller, ahead of time).  Wave w owns output columns
 // [32 NW w, 32 NW (w + 1)) of each of Q, K, V.  (the in_proj of nn.MultiheadAttention.)
 template <int D, int NP>
-__device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0, WRing<NP, kLPF, Geo<D>::kNW>& rq) {
+__device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0, ProjStream<NP, kLPF, Geo<D>::kNW>& rq) {
   using G = Geo<D>;
-  constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS;
+  constexpr int MT = G::kMT, NW = G::kNW;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int dh = D / a.H;
-  const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
-  constexpr size_t nts = (size_t)KS * 128;  // uint4 between adjacent n-tiles
-  WRing<NP, kLPF, NW> rk;
+  const WMat wm{a.wp, a.wf8};
+  ProjStream<NP, kLPF, NW> rk;
   // row -> (utterance, frame) of this lane's frames
   int rb[MT], rt[MT];
   bool ok[MT];
@@ -77,10 +122,10 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
 
   f32x16 acc[MT][NW];
   // ---- Q ----
-  ring_fill<NP, kLPF, NW>(rk, wfrag_lane<KS>(a.wp, TQ + t0), nts, KS);
+  proj_fill<D, NP, kLPF, NW>(rk, wm, TQ + t0);
   acc_init_bias<MT, NW>(acc, a.bias + 32 * t0);
-  gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(a.wp, t0), nts, rq);
-  ring_fill<NP, kLPF, NW>(rq, wfrag_lane<KS>(a.wp, 2 * TQ + t0), nts, KS);  // V weights, in flight during the K pass
+  proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, t0);
+  proj_fill<D, NP, kLPF, NW>(rq, wm, 2 * TQ + t0);  // V weights, in flight during the K pass
   {
     const float scale = kLog2e * rsqrtf((float)dh);
 #pragma unroll
@@ -101,7 +146,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
   }
   // ---- K ----
   acc_init_bias<MT, NW>(acc, a.bias + D + 32 * t0);
-  gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(a.wp, TQ + t0), nts, rk);
+  proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rk, wm, TQ + t0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     if (ok[mt]) {
@@ -119,7 +164,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
     }
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
   acc_init_bias<MT, NW>(acc, a.bias + 2 * D + 32 * t0);
-  gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(a.wp, 2 * TQ + t0), nts, rq);
+  proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, 2 * TQ + t0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     if (ok[mt]) {
@@ -309,9 +354,13 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
       const int rl = tg * kDwFrames + i;
       float vx = silu_f(acc[i].x), vy = silu_f(acc[i].y);
       if (row0 + rl >= M) vx = vy = 0.f;
-      const hl2_t sp = split2<NP>(vx, vy);
+      const hl2_t sp = split2<(NP == 1 ? 1 : 3)>(vx, vy);
       *(h2*)(smem + rl * G::kALd + c * 2) = sp.hi;
       if (NP == 3) *(h2*)(smem + G::kAPlane + rl * G::kALd + c * 2) = sp.lo;
+      if (NP == 8) {  // e5m2 bytes of the two residuals (adjacent channels are adjacent in the permuted byte plane)
+        const unsigned lb = __builtin_bit_cast(unsigned, lo8_gain(sp.lo));
+        *(unsigned short*)(smem + G::kAPlane + rl * G::kA8Ld + lo8_pos(c)) = (unsigned short)(((lb >> 8) & 0xffu) | ((lb >> 16) & 0xff00u));
+      }
     }
   }
 }
@@ -320,13 +369,11 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
 // NW column tiles [32 NW w, ..) (swapped orientation: lane = frame).  `r` holds the first kDPF k-steps.
 template <int D, int NP>
 __device__ __forceinline__ void pw2_gemm(f32x16 (&acc2)[Geo<D>::kMT][Geo<D>::kNW], const char* smem, const ProjResArgs& a,
-                                         WRing<NP, kDPF, Geo<D>::kNW>& r) {
+                                         ProjStream<NP, kDPF, Geo<D>::kNW>& r) {
   using G = Geo<D>;
-  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  const int w = wave_id();
   acc_init_bias<G::kMT, G::kNW>(acc2, a.bias + 32 * G::kNW * w);
-  const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
-  gemm_ring<NP, G::kKS, G::kNW, true, kDPF, NoSide, 0, G::kMT>(acc2, a_lane, G::kALd, G::kAPlane,
-                                                               wfrag_lane<G::kKS>(a.wp, G::kNW * w), (size_t)G::kKS * 128, r);
+  proj_gemm<D, NP, kDPF, G::kNW, G::kMT>(acc2, smem, r, WMat{a.wp, a.wf8}, G::kNW * w);
 }
 
 // swapped-orientation accumulators (lane = frame, register quad = 4 consecutive columns of this wave's tiles)

@@ -31,10 +31,11 @@ struct QkvArgs {
   const float* x;  // [M][D]
   int M, B, Tq, Tp, H, D;  // Tq = T' (frames per utterance), Tp = padded to 32
   const float *ln_g, *ln_b;
-  const uint4* wp;  // packed in_proj_weight [768][256]
-  const float* bias;  // [768]
+  const uint4* wp;  // packed in_proj_weight [3D][D]
+  const float* bias;  // [3D]
   half_t *q, *k, *vt;  // q,k: [B][H][Tp][dh]; vt: [B][H][dh][Tp] (key order permuted per 16)
   half_t* vt_lo = nullptr;  // optional: fp16 residual V - fp16(V), same layout (the PV product then runs on hi + lo)
+  const uint4* wf8 = nullptr;  // the same matrix as the f8 record stream (NP == 8)
 };
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
@@ -42,8 +43,9 @@ struct ProjResArgs {  // x += planes . W^T + bias   (attention out-proj; also th
   float* x;
   int M, D;
   const half_t *a_hi, *a_lo;  // [M][256]
-  const uint4* wp;            // packed [256][256]
+  const uint4* wp;            // packed [D][D]
   const float* bias;
+  const uint4* wf8 = nullptr;  // f8 record stream of the same matrix (NP == 8)
 };
 hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st);
 
@@ -51,9 +53,10 @@ struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,D), gate cols [D,2D
   const float* x;
   int M;
   const float *ln_g, *ln_b;
-  const uint4* wp;  // packed [512][256]
+  const uint4* wp;  // packed [2D][D]
   const float* bias;
-  half_t* g;  // [M][256] fp16
+  half_t* g;  // [M][D] fp16
+  const uint4* wf8 = nullptr;  // f8 record stream of the same matrix (NP == 8)
 };
 // fused: attention out-proj + residual -> conv LayerNorm -> pointwise-1 -> GLU (g.x is ignored: rows come from a.x)
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st);
@@ -61,9 +64,10 @@ hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipSt
 struct HeadArgs {  // out = log_softmax(x . W^T + b)
   const float* x;
   int M, V, D;
-  const uint4* wp;  // packed [V][256]
+  const uint4* wp;  // packed [V][D]
   const float* bias;
   float* out;  // [M][V]
+  const uint4* wf8 = nullptr;  // f8 record stream of the same matrix (NP == 8)
 };
 hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st);
 
@@ -73,6 +77,7 @@ constexpr int kMaxHeadExits = 16;
 struct HeadBatchArgs {
   const float* x[kMaxHeadExits];
   const uint4* wp[kMaxHeadExits];
+  const uint4* wf8[kMaxHeadExits];
   const float* bias[kMaxHeadExits];
   float* out;  // [E][M][V]
   int M, V, E, D;

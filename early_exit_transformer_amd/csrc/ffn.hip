@@ -198,12 +198,16 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // NTP = 2 tiles over the same H chunk, each pass's weight stream continuing into the next (gemm_ring_f8 CONT).
   constexpr int NH = (NP == 8 && NT2 > 2) ? NT2 / 2 : 1, NTP = NT2 / NH;
   const int lane = lane_id(), w = wave_id();
-  const int hh = lane >> 5, wl = w & 3;
+#ifndef EEC_ROLE_PAIR
+#define EEC_ROLE_PAIR 0  // experiment: 1 = both waves of a SIMD get the SAME role (waves w and w + 4 share a SIMD)
+#endif
+  const int hh = lane >> 5, wl = EEC_ROLE_PAIR ? ((w & 1) + 2 * (w >> 2)) : (w & 3);  // index inside the role (0 .. 3)
   const int w_s = wave_id_sgpr();
+  const int wl_s = EEC_ROLE_PAIR ? ((w_s & 1) + 2 * (w_s >> 2)) : (w_s & 3);  // the same index from the SGPR copy
   // wave-uniform.  The producers are the OLDER waves (0-3): issue arbitration between the two waves of a SIMD goes by
   // priority, then age, and the producers are the critical path of the chunk pipeline (measured -2.3 % forward against
   // the opposite assignment; raising their priority with s_setprio instead makes it slower)
-  const bool is_producer = w < 4;
+  const bool is_producer = EEC_ROLE_PAIR ? (w & 2) == 0 : w < 4;
   const int row0 = blockIdx.x * G::kRows;
   const int M = a.M, F = a.F;
   float* __restrict__ x = a.x;
@@ -240,7 +244,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // an XCD otherwise walk the same weight stream in lockstep and hit the same L2 channels at the same time.  Unlike a
   // rotated chunk order (EEC_FFN_ROT) this changes no arithmetic.  Measured: neutral on boxes that run the forward in
   // 2.8 ms, -9 % on a box that ran it in 3.3 ms.
+#ifdef EEC_SKEW_FINE  // experiment: 32 phases (one per CU of the XCD) of EEC_SKEW_FINE x 64 cycles
+  for (int i = 0; i < (int)((blockIdx.x >> 3) & 31); ++i) __builtin_amdgcn_s_sleep(EEC_SKEW_FINE);
+#else
   for (int i = 0; i < (int)((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(EEC_SKEW);
+#endif
 #endif
   constexpr int RNP = NP == 8 ? 1 : NP;  // the f8 stream keeps only the hi fragments in the ring
   // Everything below is instantiated ONCE PER ROLE (the tag is a compile-time bool) and the role split is the
@@ -294,8 +302,8 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   unsigned sink_front = 0;
   // ---- planes of stage 0 ----
   if constexpr (FNP != 0) {
-    WRing<FNP, kDPF, NW> rp;
-    ring_fill<FNP, kDPF, NW>(rp, wfrag_lane<KS>(a.pw2.wp, NW * w), nts, KS);
+    ProjStream<FNP, kDPF, NW> rp;
+    proj_fill<D, FNP, kDPF, NW>(rp, WMat{a.pw2.wp, a.pw2.wf8}, NW * w);
 #if EEC_WARM_SLOTS > 0
     {  // stage 0's weights are cold in this XCD's L2: fetch this workgroup's share while the conv front runs
       const WPtrs W0 = wptrs(0);
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   __syncthreads();
   TL_STAMP();  // 2: after prologue barrier
 
-  [[maybe_unused]] WRing<(QNP ? QNP : 1), kLPF, NW> rq;  // tail: first k-steps of this wave's Q weight tiles
+  [[maybe_unused]] ProjStream<(QNP ? QNP : 1), kLPF, NW> rq;  // tail: first k-steps of this wave's Q weight tiles
   unsigned sink = 0;  // keeps the L2 warm-up loads alive
   const int nslots = nchunk + 2;
   f32x16 acc2c[NH][MT][NTP];  // consumers' [rows x D/4] output accumulators (unused by producers)
@@ -351,6 +359,11 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
       auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
         const int mt = step >> 3, q = step & 7;
         const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
+#ifdef EEC_ABLATE_SILU  // timing-only build: no activation work at all (H stays uninitialised)
+        asm volatile("" ::"v"(u0), "v"(u1));
+        (void)hb, (void)keep_hi, (void)keep_lo;
+        return;
+#endif
         constexpr int SNP = NP == 1 ? 1 : 3;
         const hl2_t sp = ACT == 0 ? split2<SNP>(silu_exp2(u0), silu_exp2(u1)) : split2<SNP>(fmaxf(u0, 0.f), fmaxf(u1, 0.f));
         if ((q & 1) == 0) {
@@ -363,7 +376,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           *(h4*)dst = hi;
           if (NP == 3) *(h4*)(dst + kHPlane) = lo;
           if (NP == 8) {
-            const uint2 lb = __builtin_bit_cast(uint2, lo);
+            h4 lg;
+            lg.xy = lo8_gain(keep_lo), lg.zw = lo8_gain(sp.lo);
+            const uint2 lb = __builtin_bit_cast(uint2, lg);
             *(unsigned*)(hb + kHPlane + (mt * 32 + (lane & 31)) * kH8Ld + lo8_pos(wl * 32 + 4 * hh + (q >> 1) * 8)) =
                 __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
           }
@@ -442,11 +457,12 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
             const size_t wbytes = NP == 8 ? (size_t)(F / 32) * (D / 64) * kF8Rec * 16 : (size_t)F * D * 2 * (NP == 3 ? 2 : 1);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-              warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, w_s & 3, j, lane_t);
-              warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, w_s & 3, j, lane_t);
+              warm[j] = touch_share(NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p, wbytes, wl_s, j, lane_t);
+              warm[2 + j] = touch_share(NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p, wbytes, wl_s, j, lane_t);
             }
           } else if constexpr (QNP != 0) {
-            warm[0] = touch_share(a.qkv.wp, (size_t)3 * D * D * 2 * (QNP == 3 ? 2 : 1), w_s & 3, 0, lane_t);
+            warm[0] = QNP == 8 ? touch_share(a.qkv.wf8, (size_t)(3 * D / 32) * (D / 64) * kF8Rec * 16, wl_s, 0, lane_t)
+                               : touch_share(a.qkv.wp, (size_t)3 * D * D * 2 * (QNP == 3 ? 2 : 1), wl_s, 0, lane_t);
           }
         }
 #endif
@@ -500,7 +516,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     if constexpr (!producer) {
 #pragma unroll
       for (int h = 0; h < NH; ++h)
-        acc_to_etile<MT, NTP>(lds_e, G::kELd, acc2c[h], (w_e & 3) * 32 * NT2 + h * 32 * NTP, EEC_STAGE_FIELD(si, b2), lane_e);
+        acc_to_etile<MT, NTP>(lds_e, G::kELd, acc2c[h], wl_s * 32 * NT2 + h * 32 * NTP, EEC_STAGE_FIELD(si, b2), lane_e);
     }
     TL_STAMP();  // exchange tile written
     // the next phase's weight streams start only now, when the accumulators are dead (issued earlier, their
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     if constexpr (more) {
       start_streams(wptrs(1));
     } else if constexpr (QNP != 0) {
-      ring_fill<QNP, kLPF, NW>(rq, wfrag_lane<KS>(a.qkv.wp, NW * w), nts, KS);
+      proj_fill<D, QNP, kLPF, NW>(rq, WMat{a.qkv.wp, a.qkv.wf8}, NW * w);
     }
     __syncthreads();
     TL_STAMP();  // barrier
@@ -593,19 +609,20 @@ hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_f
   const int f = front ? np_front : 0, q = tail ? np_tail : 0;
 #ifdef EEC_CHAIN_MINIMAL  // tuning builds: only the three launches of the default (f16f8) production plan
   if (np == 8 && f == 0 && q == 3 && a.nstage == 1) return launch_chain_t<D, 8, 0, 0, 3, 1>(a, st);
-  if (np == 8 && f == 3 && q == 3 && a.nstage == 2) return launch_chain_t<D, 8, 0, 3, 3, 2>(a, st);
-  if (np == 8 && f == 3 && q == 0 && a.nstage == 1) return launch_chain_t<D, 8, 0, 3, 0, 1>(a, st);
+  if (np == 8 && f == 8 && q == 3 && a.nstage == 2) return launch_chain_t<D, 8, 0, 8, 3, 2>(a, st);
+  if (np == 8 && f == 8 && q == 0 && a.nstage == 1) return launch_chain_t<D, 8, 0, 8, 0, 1>(a, st);
   return hipErrorInvalidValue;
 #else
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
   if (np == NP_ && f == F_ && q == Q_)                                                                   \
     return a.nstage == 2 ? launch_chain_t<D, NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<D, NP_, 0, F_, Q_, 1>(a, st);
-  EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 3, 3)
+  EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 8, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 8, 3)  // f16f8 at d_model 256
+  EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 3, 3)                                                  // ... and at d_model 512
   EEC_CHAIN_CASE(3, 0, 0) EEC_CHAIN_CASE(3, 3, 0) EEC_CHAIN_CASE(3, 0, 3) EEC_CHAIN_CASE(3, 3, 3)
   EEC_CHAIN_CASE(1, 0, 0) EEC_CHAIN_CASE(1, 3, 0) EEC_CHAIN_CASE(1, 0, 3) EEC_CHAIN_CASE(1, 3, 3)
   EEC_CHAIN_CASE(1, 1, 0) EEC_CHAIN_CASE(1, 0, 1) EEC_CHAIN_CASE(1, 1, 1)
 #ifdef EEC_NP_EXPERIMENT  // diagnostic build: independent operand formats for the conv front and the in_proj tail
-  EEC_CHAIN_CASE(8, 1, 0) EEC_CHAIN_CASE(8, 0, 1) EEC_CHAIN_CASE(8, 1, 1) EEC_CHAIN_CASE(8, 1, 3) EEC_CHAIN_CASE(8, 3, 1)
+  EEC_CHAIN_CASE(8, 1, 0) EEC_CHAIN_CASE(8, 0, 1) EEC_CHAIN_CASE(8, 1, 1) EEC_CHAIN_CASE(8, 3, 8) EEC_CHAIN_CASE(8, 0, 8) EEC_CHAIN_CASE(8, 8, 8)
 #endif
 #undef EEC_CHAIN_CASE
   return hipErrorInvalidValue;

@@ -21,10 +21,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = wave_id();
   const int row0 = blockIdx.x * G::kRows;
-  WRing<NP, kLPF, G::kNW> rq;
+  ProjStream<NP, kLPF, G::kNW> rq;
   EEC_TL_STAMP(qkv, 0);
   rows_f32_to_planes<D, NP, true>(smem, a.x, row0, a.M, a.ln_g, a.ln_b, [&]() {
-    ring_fill<NP, kLPF, G::kNW>(rq, wfrag_lane<G::kKS>(a.wp, G::kNW * w), (size_t)G::kKS * 128, G::kKS);
+    proj_fill<D, NP, kLPF, G::kNW>(rq, WMat{a.wp, a.wf8}, G::kNW * w);
   });
   EEC_TL_STAMP(qkv, 1);
   __syncthreads();
@@ -35,7 +35,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
 template <int D>
 static hipError_t launch_qkv_d(const QkvArgs& a, int np, hipStream_t st) {
   using G = Geo<D>;
-  auto k = np == 3 ? qkv_kernel<D, 3> : qkv_kernel<D, 1>;
+  auto k = np == 8 ? qkv_kernel<D, 8> : np == 3 ? qkv_kernel<D, 3> : qkv_kernel<D, 1>;
   hipError_t e = ensure_max_lds((const void*)k, kLinLds<D>);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + G::kRows - 1) / G::kRows), dim3(kLinThreads), kLinLds<D>, st, a);
@@ -50,7 +50,7 @@ hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st) {
 template <int D, int NP>
 struct PlaneRegs {
   static constexpr int IT = Geo<D>::kRows * (D / 8) / kLinThreads;  // 16-byte pieces per thread per plane: 4
-  uint4 h[IT], l[NP == 3 ? IT : 1];
+  uint4 h[IT], l[NP != 1 ? IT : 1];
 };
 // issue: all global loads of the tile's pieces (rows x D/8 sixteen-byte pieces);
 // commit: the LDS writes.  Split so that a caller can queue further loads (weight ring, residual rows) behind
@@ -63,10 +63,10 @@ __device__ __forceinline__ void planes_issue512(PlaneRegs<D, NP>& pr, const half
   for (int it = 0; it < PlaneRegs<D, NP>::IT; ++it) {
     const int piece = it * kLinThreads + threadIdx.x, rl = piece / PPR, c16 = piece % PPR, row = row0 + rl;
     pr.h[it] = make_uint4(0, 0, 0, 0);
-    if (NP == 3) pr.l[it] = make_uint4(0, 0, 0, 0);
+    if (NP != 1) pr.l[it] = make_uint4(0, 0, 0, 0);
     if (row < M) {
       pr.h[it] = *(const uint4*)(hi + (size_t)row * D + c16 * 8);
-      if (NP == 3) pr.l[it] = *(const uint4*)(lo + (size_t)row * D + c16 * 8);
+      if (NP != 1) pr.l[it] = *(const uint4*)(lo + (size_t)row * D + c16 * 8);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -80,6 +80,12 @@ __device__ __forceinline__ void planes_commit512(char* lds_act, const PlaneRegs<
     const int piece = it * kLinThreads + threadIdx.x, rl = piece / PPR, c16 = piece % PPR;
     *(uint4*)(lds_act + rl * G::kALd + c16 * 16) = pr.h[it];
     if (NP == 3) *(uint4*)(lds_act + G::kAPlane + rl * G::kALd + c16 * 16) = pr.l[it];
+    if (NP == 8)  // the residual plane arrives as fp16: its top bytes (e5m2) go to the permuted byte plane, 8 k at a time
+    {
+      typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+      const h8v lg = __builtin_bit_cast(h8v, pr.l[it]) * (half_t)kF8ALoGain;  // gain-compensated (eec_device.h, kF8ALoGain)
+      *(uint2*)(lds_act + G::kAPlane + rl * G::kA8Ld + lo8_pos(c16 * 8)) = top_bytes(__builtin_bit_cast(uint4, lg));
+    }
   }
 }
 
@@ -89,7 +95,9 @@ template <int D, int NP>
 __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResArgs a) {
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ROWS = 32, PLANE = ROWS * G::kALd, NW = G::kNW;
+  constexpr int ROWS = 32, NW = G::kNW;
+  static_assert(NP != 8, "the 32-row projection keeps the fragment formats (sub-step plan, legacy layer)");
+  constexpr int PLANE = ROWS * G::kALd;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * ROWS;
   const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
@@ -138,18 +146,17 @@ constexpr int kProjGluLds = 2 * Geo<D>::kAPlane + Geo<D>::kETile;  // 134144 / 1
 template <int D, int NP>
 __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a, GluArgs gl) {
   using G = Geo<D>;
-  constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS, RPW = G::kRPW;
-  constexpr size_t nts = (size_t)KS * 128;
+  constexpr int MT = G::kMT, NW = G::kNW, RPW = G::kRPW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_e = smem + 2 * G::kAPlane;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int row0 = blockIdx.x * G::kRows;
-  const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
-  WRing<NP, kLPF, NW> r, rv;
+  ProjStream<NP, kLPF, NW> r, rv;
+  const WMat wo{a.wp, a.wf8}, wg{gl.wp, gl.wf8};
   EEC_TL_STAMP(glu, 0);
   PlaneRegs<D, NP> pr;
   planes_issue512<D, NP>(pr, a.a_hi, a.a_lo, row0, a.M);  // needed first: queued ahead of the weight ring
-  ring_fill<NP, kLPF, NW>(r, wfrag_lane<KS>(a.wp, NW * w), nts, KS);
+  proj_fill<D, NP, kLPF, NW>(r, wo, NW * w);
   // residual rows of this wave: requested now, consumed after the out-proj GEMM (their latency hides under it)
   RowV<G::kQ> xres[RPW];
 #pragma unroll
@@ -166,9 +173,9 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   {
     f32x16 acc[MT][NW];
     acc_init_bias<MT, NW>(acc, a.bias + 32 * NW * w);
-    gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(a.wp, NW * w), nts, r);
+    proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, r, wo, NW * w);
     EEC_TL_STAMP(glu, 3);
-    ring_fill<NP, kLPF, NW>(rv, wfrag_lane<KS>(gl.wp, NW * w), nts, KS);  // GLU value weights: in flight during the exchange
+    proj_fill<D, NP, kLPF, NW>(rv, wg, NW * w);  // GLU value weights: in flight during the exchange
     acc_swapped_to_etile<MT, NW>(lds_e, G::kELd, acc, 32 * NW * w);
   }
   EEC_TL_STAMP(glu, 4);
@@ -195,14 +202,14 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   __syncthreads();
   EEC_TL_STAMP(glu, 7);
   constexpr int TQ = D / 32;  // column tiles of the value half; the gate half follows
-  WRing<NP, kLPF, NW> rg;
-  ring_fill<NP, kLPF, NW>(rg, wfrag_lane<KS>(gl.wp, TQ + NW * w), nts, KS);
+  ProjStream<NP, kLPF, NW> rg;
+  proj_fill<D, NP, kLPF, NW>(rg, wg, TQ + NW * w);
   f32x16 av[MT][NW], ag[MT][NW];
   acc_init_bias<MT, NW>(av, gl.bias + 32 * NW * w);
-  gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(av, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(gl.wp, NW * w), nts, rv);
+  proj_gemm<D, NP, kLPF, NW, MT>(av, smem, rv, wg, NW * w);
   EEC_TL_STAMP(glu, 8);
   acc_init_bias<MT, NW>(ag, gl.bias + D + 32 * NW * w);
-  gemm_ring<NP, KS, NW, true, kLPF, NoSide, 0, MT>(ag, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(gl.wp, TQ + NW * w), nts, rg);
+  proj_gemm<D, NP, kLPF, NW, MT>(ag, smem, rg, wg, TQ + NW * w);
   EEC_TL_STAMP(glu, 9);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
 
 template <int D>
 static hipError_t launch_proj_glu_d(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
-  auto k = np == 3 ? proj_glu_kernel<D, 3> : proj_glu_kernel<D, 1>;
+  auto k = np == 8 ? proj_glu_kernel<D, 8> : np == 3 ? proj_glu_kernel<D, 3> : proj_glu_kernel<D, 1>;
   hipError_t e = ensure_max_lds((const void*)k, kProjGluLds<D>);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(kLinThreads), kProjGluLds<D>, st, a, g);
@@ -248,19 +255,19 @@ constexpr int kHeadLds = kLinLds<D> > Geo<D>::kRows * kHeadELd ? kLinLds<D> : Ge
 template <int D, int NP>
 __device__ __forceinline__ void head_body(char* smem, const HeadArgs& a) {
   using G = Geo<D>;
-  constexpr int MT = G::kMT, KS = G::kKS, RPW = G::kRPW;
-  const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
+  constexpr int MT = G::kMT, RPW = G::kRPW;
+  const int lane = lane_id(), w = wave_id();
   const int row0 = blockIdx.x * G::kRows;
-  const char* a_lane = smem + (lane & 31) * G::kALd + hh * 16;
   const bool active = 32 * w < a.V;  // wave-uniform
-  WRing<NP, kLPF> r;
+  const WMat wm{a.wp, a.wf8};
+  ProjStream<NP, kLPF, 1> r;
   rows_f32_to_planes<D, NP, false>(smem, a.x, row0, a.M, nullptr, nullptr,
-                                   [&]() { if (active) ring_fill<NP, kLPF, 1>(r, wfrag_lane<KS>(a.wp, w), 0, KS); });
+                                   [&]() { if (active) proj_fill<D, NP, kLPF, 1>(r, wm, w); });
   __syncthreads();
   f32x16 acc[MT][1];
   if (active) {
     acc_init_bias<MT, 1>(acc, a.bias + 32 * w);
-    gemm_ring<NP, KS, 1, true, kLPF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(a.wp, w), 0, r);
+    proj_gemm<D, NP, kLPF, 1, MT>(acc, smem, r, wm, w);
   }
   // logits -> fp32 exchange tile (over the dead activation planes) -> each wave finishes RPW whole frames: the
   // log-sum-exp is a wave reduction and every output row leaves as one contiguous store (V * 4 bytes)
@@ -292,13 +299,13 @@ template <int D, int NP>
 __global__ __launch_bounds__(kLinThreads, 2) void head_batch_kernel(HeadBatchArgs b) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int e = blockIdx.y;
-  const HeadArgs a{b.x[e], b.M, b.V, b.D, b.wp[e], b.bias[e], b.out + (size_t)e * b.M * b.V};
+  const HeadArgs a{b.x[e], b.M, b.V, b.D, b.wp[e], b.bias[e], b.out + (size_t)e * b.M * b.V, b.wf8[e]};
   head_body<D, NP>(smem, a);
 }
 
 template <int D>
 static hipError_t launch_head_d(const HeadArgs& a, int np, hipStream_t st) {
-  auto k = np == 3 ? head_kernel<D, 3> : head_kernel<D, 1>;
+  auto k = np == 8 ? head_kernel<D, 8> : np == 3 ? head_kernel<D, 3> : head_kernel<D, 1>;
   hipError_t e = ensure_max_lds((const void*)k, kHeadLds<D>);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(kLinThreads), kHeadLds<D>, st, a);
@@ -310,7 +317,7 @@ hipError_t launch_head(const HeadArgs& a, int np, hipStream_t st) {
 
 template <int D>
 static hipError_t launch_head_batch_d(const HeadBatchArgs& a, int np, hipStream_t st) {
-  auto k = np == 3 ? head_batch_kernel<D, 3> : head_batch_kernel<D, 1>;
+  auto k = np == 8 ? head_batch_kernel<D, 8> : np == 3 ? head_batch_kernel<D, 3> : head_batch_kernel<D, 1>;
   hipError_t e = ensure_max_lds((const void*)k, kHeadLds<D>);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows, a.E), dim3(kLinThreads), kHeadLds<D>, st, a);

@@ -69,7 +69,7 @@ __global__ void pack_frags_f8_kernel(const float* __restrict__ w, int N, int K, 
       const int k = 64 * g + 16 * q + 8 * h + j;
       const float v = (n < N) ? w[(size_t)n * K + k] * scale : 0.f;
       hi[j] = to_half_sat(v);
-      lo[8 * q + j] = v - (float)hi[j];
+      lo[8 * q + j] = (v - (float)hi[j]) * kF8WLoGain;  // gain: compensates the truncation of its partner a_hi8 (eec_device.h)
     }
     o[q * 64 + lane] = __builtin_bit_cast(uint4, hi);
   }
@@ -81,7 +81,7 @@ __global__ void pack_frags_f8_kernel(const float* __restrict__ w, int N, int K, 
     for (int kk = 0; kk < 32; ++kk) {
       const int k = 64 * g + 32 * b + kk;
       const float v = (n < N) ? w[(size_t)n * K + k] * scale : 0.f;
-      m = fmaxf(m, fabsf(v - (float)to_half_sat(v)));
+      m = fmaxf(m, fabsf(v - (float)to_half_sat(v)) * kF8WLoGain);
     }
     int e = 0;
     if (m > 0.f) e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xffu) - 127 - 14;  // scaled max lands in [2^14, 2^15)

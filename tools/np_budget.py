@@ -28,8 +28,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         errs.append((got - want).abs().max().item())
     print("RESULT " + json.dumps(errs))
     sys.exit(0)
-for ov in ["", "qkv=1", "att=1", "glu=1", "front=1", "head=1", "qkv=1,att=1", "qkv=1,front=1", "qkv=1,att=1,front=1",
-           "qkv=1,att=1,glu=1,front=1", "qkv=1,att=1,glu=1,front=1,head=1"]:
+DEFAULT = ["", "qkv=1", "att=1", "glu=1", "front=1", "head=1", "qkv=1,att=1", "qkv=1,front=1", "qkv=1,att=1,front=1",
+           "qkv=1,att=1,glu=1,front=1", "qkv=1,att=1,glu=1,front=1,head=1"]
+for ov in (sys.argv[1:] or DEFAULT):  # e.g. "head=3" "head=3,qkv=3": formats (1, 3, 8) per GEMM group
+    ov = "" if ov == "default" else ov
     env = dict(os.environ, EEC_NP_OVERRIDE=ov)
     out = subprocess.run([sys.executable, __file__, "--child"], env=env, capture_output=True, text=True).stdout
     res = [l for l in out.splitlines() if l.startswith("RESULT")]
