@@ -253,10 +253,15 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     const PackedLayer& L = enc->layers[li];
     const bool last = li + 1 == l1;
     AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
-    TIMED(KC_ATTN, launch_attention(at, np.att == 1 ? 1 : 3, st));
     ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
     GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g, L.conv_pw1_f8};
-    TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
+    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1)) {
+      // two launches per layer: the attention of a row tile runs in the prologue of the out_proj / GLU kernel
+      TIMED(KC_PROJ_GLU, launch_attn_proj_glu(at, pr, ga, np.glu, st));
+    } else {
+      TIMED(KC_ATTN, launch_attention(at, np.att == 1 ? 1 : 3, st));
+      TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
+    }
     ChainArgs ca{};
     ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = last ? 1 : 2;
     ca.dw = DwArgs{b.g, B, Tq, L.dw_wfold, L.dw_bfold, b.p_hi, b.p_lo};

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(512, 2) void dw_pw2_kernel(DwArgs d, ProjResArgs a)
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = wave_id();
-  const int row0 = blockIdx.x * G::kRows;
+  const int row0 = row_tile_index() * G::kRows;
   const int M = a.M;
   EEC_TL_STAMP(dw, 0);
   ProjStream<NP, kDPF, G::kNW> r;

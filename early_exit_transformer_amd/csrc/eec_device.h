@@ -64,6 +64,23 @@ struct Geo {
   static constexpr int kETile = kRows * kELd;   // 66560 / 66048
 };
 
+// Row tile of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share an XCD and its
+// L2); consecutive row tiles -- the four tiles of an utterance at T' = 256 -- exchange data between launches (K / V of the
+// utterance, the +-15-frame halo of the depthwise conv) and every tile re-reads its own residual rows in the next launch.
+// EEC_XCD_TILES: inside each group of 32 blocks, XCD x (= b % 8) gets the four CONSECUTIVE tiles 4x .. 4x+3, and the same
+// map is used by every row-tile kernel, so that traffic is served by the XCD's own L2 instead of the fabric.  Speed only:
+// correctness does not depend on the placement (kernel boundaries order all global traffic).
+#ifndef EEC_XCD_TILES
+#define EEC_XCD_TILES 1
+#endif
+__device__ __forceinline__ int row_tile_index() {
+  const int b = blockIdx.x;
+#if EEC_XCD_TILES
+  const int full = (int)(gridDim.x & ~31u);  // blocks in whole groups of 32; a ragged tail keeps the identity map
+  if (b < full) return (b & ~31) + (b & 7) * 4 + ((b >> 3) & 3);
+#endif
+  return b;
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // Lane index recomputed from nothing (v_mbcnt of the full mask) behind an optimisation barrier: code after a long

@@ -61,6 +61,12 @@ struct GluArgs {  // g = GLU(LN(x) . W^T + b): value cols [0,D), gate cols [D,2D
 // fused: attention out-proj + residual -> conv LayerNorm -> pointwise-1 -> GLU (g.x is ignored: rows come from a.x)
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st);
 
+struct AttnArgs;
+// attention + out_proj + residual -> LN -> pointwise-1 -> GLU in ONE launch (the O planes never leave the CU); only for
+// shapes where attn_fusable() holds (8 heads, T' a multiple of the row tile: every tile inside one utterance)
+bool attn_fusable(const AttnArgs& at, int D);
+hipError_t launch_attn_proj_glu(const AttnArgs& at, const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st);
+
 struct HeadArgs {  // out = log_softmax(x . W^T + b)
   const float* x;
   int M, V, D;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // priority, then age, and the producers are the critical path of the chunk pipeline (measured -2.3 % forward against
   // the opposite assignment; raising their priority with s_setprio instead makes it slower)
   const bool is_producer = EEC_ROLE_PAIR ? (w & 2) == 0 : w < 4;
-  const int row0 = blockIdx.x * G::kRows;
+  const int row0 = row_tile_index() * G::kRows;
   const int M = a.M, F = a.F;
   float* __restrict__ x = a.x;
   char* lds_h = smem + 2 * kAPlane;  // H[buf][plane][rows][136]

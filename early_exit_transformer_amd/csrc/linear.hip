@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void qkv_kernel(QkvArgs a) {
   using G = Geo<D>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int w = wave_id();
-  const int row0 = blockIdx.x * G::kRows;
+  const int row0 = row_tile_index() * G::kRows;
   ProjStream<NP, kLPF, G::kNW> rq;
   EEC_TL_STAMP(qkv, 0);
   rows_f32_to_planes<D, NP, true>(smem, a.x, row0, a.M, a.ln_g, a.ln_b, [&]() {
@@ -143,30 +143,196 @@ hipError_t launch_proj_residual(const ProjResArgs& a, int np, hipStream_t st) {
 template <int D>
 constexpr int kProjGluLds = 2 * Geo<D>::kAPlane + Geo<D>::kETile;  // 134144 / 132608
 
+// Attention of one row tile straight into the activation planes of the out-proj product (the fused launch below).
+// Preconditions (checked by the launcher): 8 heads -- wave w IS head w --, T' a multiple of the tile's rows, so all of
+// the tile's queries belong to ONE utterance and T' needs no key padding.  The products are those of attn_kernel
+// (attention.hip): S^T = K . Q^T and O^T += V^T . P^T with the query on the MFMA lane, online softmax over blocks of
+// 64 keys, keys >= enc_len masked; but K and V^T fragments come straight from global memory (they are contiguous 2 KiB /
+// 64-B-per-row pieces, read by the four workgroups of the utterance out of L2), double-buffered in registers: there is
+// no LDS staging, no barrier, and the normalised O never leaves the CU -- it is split hi / lo and written into the
+// LDS planes at columns [32 w .. ) of the tile's rows.
 template <int D, int NP>
-__global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a, GluArgs gl) {
+__device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& a, int row0) {
+  using G = Geo<D>;
+  constexpr int MT = G::kMT, DH = D / 8, KSQ = DH / 16, DT = DH / 32, KB = 2;
+  constexpr float kNegBig = -1.0e30f;
+  const int lane = lane_id(), w = wave_id(), r = lane & 31, hh = lane >> 5;
+  const int b = row0 / a.Tq, q0 = row0 - b * a.Tq, bh = b * a.H + w;
+  const int len = min(a.enc_len[b], a.Tq);
+  const bool v2 = a.vt_lo != nullptr;  // uniform
+  h8 qf[MT][KSQ];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + mt * 32 + r) * DH + 8 * hh;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) qf[mt][ks] = *(const h8*)(qp + ks * 16);
+  }
+  f32x16 o[MT][DT];
+  float m_run[MT], l_run[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    m_run[mt] = kNegBig, l_run[mt] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[mt][dt][i] = 0.f;
+  }
+  const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
+  const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
+  const half_t* vlbase = v2 ? a.vt_lo + (size_t)bh * DH * a.Tp : vbase;
+  const int nkt = (len + 31) / 32;
+  struct Blk {  // K and V^T fragments of one block of KB key tiles
+    h8 k[KB][KSQ], v[KB][DT][2], vl[KB][DT][2];
+  };
+  const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto fetch = [&](Blk& f, int kt0) {
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int kt = min(kt0 + j, nkt - 1);  // a tile past the end is re-read and masked away below
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) f.k[j][ks] = *(const h8*)(kbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const size_t off = (size_t)(dt * 32 + r) * a.Tp + kt * 32 + ks * 16 + 8 * hh;
+          f.v[j][dt][ks] = *(const h8*)(vbase + off);
+          f.vl[j][dt][ks] = v2 ? *(const h8*)(vlbase + off) : zero8;
+        }
+    }
+  };
+  auto block = [&](const Blk& f, int kt0) {
+    f32x16 sc[KB][MT];
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[j][mt][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) sc[j][mt] = mfma16(f.k[j][ks], qf[mt][ks], sc[j][mt]);
+      }
+    const int key0 = kt0 * 32;
+    if (key0 + KB * 32 > len) {  // block touches the masked tail (or runs past the last tile): wave-uniform test
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (key0 + j * 32 + acc_row(i, lane) >= len || kt0 + j >= nkt) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) sc[j][mt][i] = kNegBig;
+          }
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      float tmax = kNegBig;
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[j][mt][i]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+      const float m_new = fmaxf(m_run[mt], tmax);
+      const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_new);
+      m_run[mt] = m_new;
+      float psum = 0.f;
+      h8 pf[KB][2];
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float p = __builtin_amdgcn_exp2f(sc[j][mt][i] - m_new);
+          psum += p;
+          pf[j][i >> 3][i & 7] = (half_t)p;
+        }
+      l_run[mt] = l_run[mt] * alpha + psum;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][dt][i] *= alpha;
+#pragma unroll
+        for (int j = 0; j < KB; ++j)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            o[mt][dt] = mfma16(f.v[j][dt][ks], pf[j][ks], o[mt][dt]);
+            if (v2) o[mt][dt] = mfma16(f.vl[j][dt][ks], pf[j][ks], o[mt][dt]);
+          }
+      }
+    }
+  };
+  Blk fa, fb;
+  if (nkt > 0) fetch(fa, 0);
+  for (int kt0 = 0; kt0 < nkt; kt0 += 2 * KB) {
+    if (kt0 + KB < nkt) fetch(fb, kt0 + KB);
+    block(fa, kt0);
+    if (kt0 + KB < nkt) {
+      if (kt0 + 2 * KB < nkt) fetch(fa, kt0 + 2 * KB);
+      block(fb, kt0 + KB);
+    }
+  }
+  // normalise and write the planes.  No valid key at all (length 0): the installed torch returns zeros ("safe softmax").
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const float l_tot = l_run[mt] + __shfl_xor(l_run[mt], 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int rl = mt * 32 + r;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = w * DH + dt * 32 + 8 * g + 4 * hh;
+        const hl2_t s0 = split2<(NP == 1 ? 1 : 3)>(o[mt][dt][4 * g] * inv, o[mt][dt][4 * g + 1] * inv);
+        const hl2_t s1 = split2<(NP == 1 ? 1 : 3)>(o[mt][dt][4 * g + 2] * inv, o[mt][dt][4 * g + 3] * inv);
+        h4 hi, lo;
+        hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
+        *(h4*)(smem + rl * G::kALd + col * 2) = hi;
+        if (NP == 3) *(h4*)(smem + G::kAPlane + rl * G::kALd + col * 2) = lo;
+        if (NP == 8) {
+          h4 lg;
+          lg.xy = lo8_gain(s0.lo), lg.zw = lo8_gain(s1.lo);
+          const uint2 lb = __builtin_bit_cast(uint2, lg);
+          *(unsigned*)(smem + G::kAPlane + rl * G::kA8Ld + lo8_pos(col)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+        }
+      }
+  }
+}
+
+// FUSED: the tile's attention runs in the prologue (attn_tile_to_planes) instead of loading the O planes a separate
+// attention launch wrote: two launches per Conformer layer instead of three, no O round trip through HBM.
+template <int D, int NP, bool FUSED>
+__global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a, GluArgs gl, AttnArgs at) {
   using G = Geo<D>;
   constexpr int MT = G::kMT, NW = G::kNW, RPW = G::kRPW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* lds_e = smem + 2 * G::kAPlane;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
-  const int row0 = blockIdx.x * G::kRows;
+  const int row0 = row_tile_index() * G::kRows;
   ProjStream<NP, kLPF, NW> r, rv;
   const WMat wo{a.wp, a.wf8}, wg{gl.wp, gl.wf8};
   EEC_TL_STAMP(glu, 0);
-  PlaneRegs<D, NP> pr;
-  planes_issue512<D, NP>(pr, a.a_hi, a.a_lo, row0, a.M);  // needed first: queued ahead of the weight ring
-  proj_fill<D, NP, kLPF, NW>(r, wo, NW * w);
-  // residual rows of this wave: requested now, consumed after the out-proj GEMM (their latency hides under it)
   RowV<G::kQ> xres[RPW];
+  if constexpr (FUSED) {
+    attn_tile_to_planes<D, NP>(smem, at, row0);
+    proj_fill<D, NP, kLPF, NW>(r, wo, NW * w);
 #pragma unroll
-  for (int i = 0; i < RPW; ++i) {
-    const int row = row0 + w * RPW + i;
-    xres[i] = zero_row<G::kQ>();
-    if (row < a.M) xres[i] = load_row<D>(a.x + (size_t)row * D, lane);
+    for (int i = 0; i < RPW; ++i) {
+      const int row = row0 + w * RPW + i;
+      xres[i] = zero_row<G::kQ>();
+      if (row < a.M) xres[i] = load_row<D>(a.x + (size_t)row * D, lane);
+    }
+  } else {
+    PlaneRegs<D, NP> pr;
+    planes_issue512<D, NP>(pr, a.a_hi, a.a_lo, row0, a.M);  // needed first: queued ahead of the weight ring
+    proj_fill<D, NP, kLPF, NW>(r, wo, NW * w);
+    // residual rows of this wave: requested now, consumed after the out-proj GEMM (their latency hides under it)
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = row0 + w * RPW + i;
+      xres[i] = zero_row<G::kQ>();
+      if (row < a.M) xres[i] = load_row<D>(a.x + (size_t)row * D, lane);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    planes_commit512<D, NP>(smem, pr);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  planes_commit512<D, NP>(smem, pr);
   EEC_TL_STAMP(glu, 1);
   __syncthreads();
   EEC_TL_STAMP(glu, 2);
@@ -234,16 +400,27 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   EEC_TL_STAMP(glu, 10);
 }
 
-template <int D>
-static hipError_t launch_proj_glu_d(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
-  auto k = np == 8 ? proj_glu_kernel<D, 8> : np == 3 ? proj_glu_kernel<D, 3> : proj_glu_kernel<D, 1>;
+template <int D, bool FUSED>
+static hipError_t launch_proj_glu_d(const ProjResArgs& a, const GluArgs& g, const AttnArgs& at, int np, hipStream_t st) {
+  auto k = np == 8 ? proj_glu_kernel<D, 8, FUSED> : np == 3 ? proj_glu_kernel<D, 3, FUSED> : proj_glu_kernel<D, 1, FUSED>;
   hipError_t e = ensure_max_lds((const void*)k, kProjGluLds<D>);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(kLinThreads), kProjGluLds<D>, st, a, g);
+  hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(kLinThreads), kProjGluLds<D>, st, a, g, at);
   return hipGetLastError();
 }
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
-  return a.D == 512 ? launch_proj_glu_d<512>(a, g, np, st) : launch_proj_glu_d<256>(a, g, np, st);
+  const AttnArgs none{};
+  return a.D == 512 ? launch_proj_glu_d<512, false>(a, g, none, np, st) : launch_proj_glu_d<256, false>(a, g, none, np, st);
+}
+// attention + out_proj + LN + pointwise-1 + GLU in one launch; usable when attn_fusable() holds
+bool attn_fusable(const AttnArgs& at, int D) {
+  // d_model 512 (head dim 64) is left to the separate attention launch: two double-buffered K / V^T fragment sets of that
+  // size do not fit the register file beside the accumulators
+  return D == 256 && at.H == 8 && at.dh * 8 == D && at.Tq % Geo<256>::kRows == 0 && at.Tp == at.Tq;
+}
+hipError_t launch_attn_proj_glu(const AttnArgs& at, const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
+  if (!attn_fusable(at, a.D)) return hipErrorInvalidValue;
+  return launch_proj_glu_d<256, true>(a, g, at, np, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -257,7 +434,7 @@ __device__ __forceinline__ void head_body(char* smem, const HeadArgs& a) {
   using G = Geo<D>;
   constexpr int MT = G::kMT, RPW = G::kRPW;
   const int lane = lane_id(), w = wave_id();
-  const int row0 = blockIdx.x * G::kRows;
+  const int row0 = row_tile_index() * G::kRows;
   const bool active = 32 * w < a.V;  // wave-uniform
   const WMat wm{a.wp, a.wf8};
   ProjStream<NP, kLPF, 1> r;
