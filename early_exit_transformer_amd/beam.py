@@ -1,0 +1,116 @@
+"""Decoders on top of the HIP encoder: mirrors of the reference's ``util/beam_infer.py`` pieces that this package can
+serve without torchaudio.
+
+* ``GreedyCTCDecoder``            util/beam_infer.py:9-24, on the batched HIP kernel (``eec_greedy_ctc``).
+* ``BeamInference.beam_search``   util/beam_infer.py:198-307: the AED beam search that ``inference.py:44-51`` drives per
+  utterance and exit.  Same signature, same arithmetic and the same quirks (the length penalty DIVIDES the step's
+  log-probs; ``min_length`` defaults to 300, so EOS never finalises a beam inside ``max_length`` steps; the best beam
+  is the one with the highest accumulated score), but the candidate bookkeeping runs as tensor ops on the device
+  instead of a Python loop over beams, and ``decode_all_exits`` runs the encoder ONCE for all exits (one
+  ``eec_encoder_forward`` with taps) where the reference re-runs the first n exit groups for every n
+  (inference.py:44-46: O(E^2) groups per utterance).  The decoder itself stays the reference's
+  ``nn.TransformerDecoder`` on PyTorch-ROCm (model._decoder_).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from .model import greedy_ctc
+
+
+class GreedyCTCDecoder(torch.nn.Module):
+    """``forward(emission[T', V]) -> List[int]``: argmax, collapse repeats, drop blank (util/beam_infer.py:9-24)."""
+
+    def __init__(self, blank: int = 0):
+        super().__init__()
+        self.blank = blank
+
+    def forward(self, emission: Tensor) -> List[int]:
+        tokens, counts = greedy_ctc(emission.unsqueeze(0), self.blank)
+        return tokens[0, : int(counts[0])].tolist()
+
+
+def sequence_length_penalty(length: int, alpha: float = 0.6) -> float:
+    """util/beam_infer.py:194-195."""
+    return ((5 + length) / (5 + 1)) ** alpha
+
+
+class BeamInference:
+    """``args`` needs ``dec_voc_size, trg_sos_idx, trg_eos_idx, trg_pad_idx, beam_size, pen_alpha, device`` (the fields
+    util/conf.py:455-486 injects); every one of them can also be given per call, as in the reference."""
+
+    def __init__(self, args=None):
+        self.args = args
+
+    sequence_length_penalty = staticmethod(sequence_length_penalty)
+
+    def _arg(self, value, name):
+        if value is not None:
+            return value
+        if self.args is None or not hasattr(self.args, name):
+            raise ValueError(f"beam_search: {name} was not given and there is no args.{name}")
+        return getattr(self.args, name)
+
+    @torch.no_grad()
+    def beam_search(self, model, encoder_output: Tensor, layer_n: int, vocab_size: Optional[int] = None, max_length: int = 500,
+                    min_length: int = 300, SOS_token: Optional[int] = None, EOS_token: Optional[int] = None,
+                    PAD_token: Optional[int] = None, beam_size: Optional[int] = None, pen_alpha: Optional[float] = None,
+                    return_best_beam: bool = True):
+        """Returns ``(final_tokens, final_scores, best_tokens)`` like the reference: lists of 1-D token tensors / 0-D score
+        tensors, and the best beam as a Python list (SOS included)."""
+        V = self._arg(vocab_size, "dec_voc_size")
+        sos, eos = self._arg(SOS_token, "trg_sos_idx"), self._arg(EOS_token, "trg_eos_idx")
+        self._arg(PAD_token, "trg_pad_idx")  # accepted and unused, as in the reference
+        beam = self._arg(beam_size, "beam_size")
+        alpha = self._arg(pen_alpha, "pen_alpha")
+        dev = encoder_output.device
+        count = beam
+        tokens = torch.tensor([[sos]], dtype=torch.long, device=dev)  # [live beams, s]
+        scores = torch.zeros(1, dtype=torch.float32, device=dev)
+        final_tokens: List[Tensor] = []
+        final_scores: List[Tensor] = []
+        i = -1
+        for i in range(max_length):
+            enc = encoder_output if i == 0 else encoder_output.expand(tokens.size(0), *encoder_output.shape[1:])
+            logp = model._decoder_(tokens, enc, layer_n)[:, -1] / sequence_length_penalty(i + 1, alpha)
+            cand, idx = torch.topk((scores.unsqueeze(1) + logp).reshape(-1), count)
+            beam_idx = torch.div(idx, V, rounding_mode="floor")
+            tok_idx = torch.remainder(idx, V)
+            grown = torch.cat([tokens[beam_idx], tok_idx.unsqueeze(1)], dim=1)
+            done = (tok_idx == eos) & (i > min_length)  # never true while max_length <= min_length (the reference's defaults)
+            if bool(done.any()):
+                for j in torch.nonzero(done).flatten().tolist():
+                    final_tokens.append(grown[j])
+                    final_scores.append(cand[j])
+                    count -= 1
+                grown, cand = grown[~done], cand[~done]
+            scores = cand
+            if len(final_scores) == beam:
+                break
+            tokens = grown
+        if i == max_length - 1:  # ran out of steps: every live beam is final
+            for t, s in zip(tokens, scores):
+                final_tokens.append(t)
+                final_scores.append(s)
+            assert len(final_tokens) == beam and len(final_scores) == beam, \
+                "Final_tokens and final_scores lists do not match beam_size size!"
+        best = None
+        if return_best_beam:
+            best = final_tokens[int(torch.stack(final_scores).argmax())].tolist()
+        return final_tokens, final_scores, best
+
+    @torch.no_grad()
+    def decode_all_exits(self, model, spec: Tensor, valid_len: Tensor, max_length: Optional[int] = None, beam_size: int = 10,
+                         **kw) -> List[List[int]]:
+        """What inference.py:31-51 does for ONE utterance: the best beam of every exit.  ``spec`` [n_mels, T],
+        ``valid_len`` 0-D / [1].  The encoder runs once (taps of all exits)."""
+        T = spec.size(1)
+        if max_length is None:  # inference.py:31-39 (p = 30, m = 5 / 200)
+            max_length = int(30 - T * 5 / 200) if T < 200 else int(T / 12)
+        taps = model._run_encoder(spec.unsqueeze(0), valid_len.reshape(1), want_out=False, want_taps=True,
+                                  n_groups=model._cfg.n_exits)[1]
+        return [self.beam_search(model, taps[n - 1], n, max_length=max_length, beam_size=beam_size, **kw)[2]
+                for n in range(1, model._cfg.n_exits + 1)]

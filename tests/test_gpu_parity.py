@@ -551,6 +551,44 @@ def test_aed_greedy_tokens_golden():
     assert compared >= 0.8 * total, f"only {compared}/{total} decode steps had safe margins"
 
 
+def test_aed_beam_search_golden():
+    """inference.py:18-62 (evaluate_batch_ae) end to end on the product: ONE HIP encoder run for all exits, the reference's
+    nn.TransformerDecoder on PyTorch-ROCm, BeamInference.beam_search (beam 10) on the device.  Fixture: the reference's
+    full_conformer on CPU driven by its beam-search algorithm restated with its own loops (make_golden.aed_beam_search).
+    Candidates near the beam boundary can swap under 1e-3 log-prob noise, so the final scores are compared as sorted
+    values, and the best token sequence wherever its score leads the runner-up by a safe margin."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    from early_exit_transformer_amd.beam import BeamInference
+    z = np.load(os.path.join(GOLDEN, "aed_greedy.npz"))
+    kw = eval(str(z["kwargs"]))
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=int(z["n_dec_layers"]), **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, int(z["seed"])), strict=True)
+    fc = fc.cuda()
+    inf = BeamInference()
+    best_checked = 0
+    for i, (T, seed) in enumerate(eval(str(z["cases"]))):
+        mel, length = synth.synth_mel(1, 80, T, seed=seed)[0].cuda(), torch.tensor(T)
+        taps = fc._run_encoder(mel.unsqueeze(0), length.reshape(1), want_out=False, want_taps=True, n_groups=kw["n_enc_exits"])[1]
+        for n in range(1, kw["n_enc_exits"] + 1):
+            ft, fs, best = inf.beam_search(fc, taps[n - 1], n, vocab_size=256, max_length=G.aed_max_length(T), SOS_token=1,
+                                           EOS_token=2, PAD_token=126, beam_size=10, pen_alpha=1.0)
+            got = torch.stack(fs).cpu().numpy()
+            want = z[f"beam_scores{i}"][n - 1]
+            assert np.abs(np.sort(got) - np.sort(want)).max() < 2e-2, (i, n)
+            order = np.argsort(-want)
+            if want[order[0]] - want[order[1]] > 2e-2:
+                assert best == z[f"beam_best{i}"][n - 1].tolist(), (i, n)
+                best_checked += 1
+        all_best = inf.decode_all_exits(fc, mel, length, beam_size=10, vocab_size=256, SOS_token=1, EOS_token=2, PAD_token=126, pen_alpha=1.0)
+        assert len(all_best) == kw["n_enc_exits"] and all(len(b) == 1 + G.aed_max_length(T) for b in all_best)
+    assert best_checked >= 6, best_checked
+
+
 def _product_rank(rank, world, port, q):
     import os
     import torch.distributed as dist

@@ -162,3 +162,49 @@ def test_bench_parent_makes_no_gpu_call_before_spawning():
     assert main.index("launch_ranks(args.gpus") < main.index("torch.cuda.")
     launcher = src[src.index("def launch_ranks"):src.index("def plumbing_check")]
     assert "torch.cuda" not in launcher and "import torch" not in launcher
+
+
+class _ToyDecoderModel:
+    """A deterministic stand-in for ``model._decoder_``: log-probs depend on the whole prefix, so beam bookkeeping errors
+    (wrong parent beam, wrong order) change the result."""
+
+    def __init__(self, V=11, seed=0):
+        g = torch.Generator().manual_seed(seed)
+        self.emb = torch.randn(V, 16, generator=g)
+        self.out = torch.randn(16, V, generator=g) * 2
+
+    def _decoder_(self, trg, enc, layer_n):
+        h = torch.cumsum(self.emb[trg] * torch.linspace(1.0, 2.0, trg.size(1)).view(1, -1, 1), dim=1) + enc.mean(dim=1, keepdim=True)[..., :16]
+        return torch.log_softmax(torch.tanh(h) @ self.out * (1.0 + 0.1 * layer_n), dim=-1)
+
+
+@pytest.mark.parametrize("min_length,max_length,beam", [(300, 12, 5), (2, 12, 5), (0, 9, 3), (4, 6, 4)])
+def test_beam_search_equals_the_reference_algorithm(min_length, max_length, beam):
+    """early_exit_transformer_amd.beam.BeamInference.beam_search (tensor ops) against the reference's algorithm restated
+    with its own Python loops (util/beam_infer.py:198-307; tests/golden/make_golden.py aed_beam_search), including the
+    EOS-finalisation branch the reference's defaults never reach (min_length = 300)."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    from early_exit_transformer_amd.beam import BeamInference
+    V, eos = 11, 2
+    model = _ToyDecoderModel(V)
+    enc = torch.randn(1, 7, 16, generator=torch.Generator().manual_seed(1))
+    inf = BeamInference()
+    hit_eos = False
+    for layer_n in (1, 3):
+        want_t, want_s, want_best, _ = G.aed_beam_search(model, enc, layer_n, max_length, beam_size=beam, alpha=1.0, sos=1, eos=eos,
+                                                         V=V, min_length=min_length)
+        got_t, got_s, got_best = inf.beam_search(model, enc, layer_n, vocab_size=V, max_length=max_length, min_length=min_length,
+                                                 SOS_token=1, EOS_token=eos, PAD_token=0, beam_size=beam, pen_alpha=1.0)
+        assert got_best == want_best
+        assert len(got_t) == len(want_t)
+        for a, b in zip(got_t, want_t):
+            assert a.tolist() == b.tolist()
+        assert torch.allclose(torch.stack(got_s), torch.stack(want_s), atol=1e-6)
+        hit_eos = hit_eos or any(len(t) < max_length + 1 for t in want_t)
+    if min_length <= 2:
+        assert hit_eos, "the EOS branch must be exercised when min_length allows it"
+    if min_length >= max_length:
+        assert not hit_eos
