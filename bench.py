@@ -267,6 +267,28 @@ def main():
         del m3
         torch.cuda.empty_cache()
 
+    # ---- mel front end: waveform -> [B, 80, T] power mel for the same batch (secondary line) ----
+    frontend = None
+    if rank == 0 and world == 1 and not args.no_modes:
+        from early_exit_transformer_amd.frontend import MelFrontend
+        fe = MelFrontend()
+        n_samples = (T - 1) * 160  # the waveform length whose front end yields T mel frames
+        wave = torch.randn(B, n_samples, device=dev) * 0.1
+        for _ in range(3):
+            fe(wave)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_fe = max(5, args.steps // 2)
+        for _ in range(n_fe):
+            fe(wave)
+        torch.cuda.synchronize()
+        d = (time.perf_counter() - t1) / n_fe
+        frontend = {"workload": f"{B} x {n_samples} samples (16 kHz) -> mel [{B}, 80, {T}]: 1024-point power spectrum (exact-fp32 MFMA DFT) + 80 mel filters",
+                    "ms": round(d * 1e3, 4), "mel_frames_per_s": round(B * T / d, 1),
+                    "audio_seconds_per_second": round(B * n_samples / 16000.0 / d, 1),
+                    "fp32_flop": 2.0 * B * T * (320 * 1024 + 1026), "frac_of_fp32_mfma_peak": round(2.0 * B * T * (320 * 1024 + 1026) / d / 157.3e12, 4)}
+        del wave
+
     # HBM-side bytes per FFN launch from the committed PMC passes of this round (rocprofv3 --pmc FETCH_SIZE /
     # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
     # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
@@ -392,7 +414,7 @@ def main():
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
-            "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3,
+            "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3, "frontend": frontend,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -62,7 +62,8 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy",
            "eec_encoder_forward_prefix", "eec_encoder_group_workspace_bytes", "eec_encoder_group_forward",
            "eec_encoder_head_forward", "eec_encoder_stem1_forward", "eec_encoder_lengths",
-           "eec_ctc_backward_workspace_bytes", "eec_ctc_loss_forward", "eec_ctc_loss_backward", "eec_logsoftmax_backward"]
+           "eec_ctc_backward_workspace_bytes", "eec_ctc_loss_forward", "eec_ctc_loss_backward", "eec_logsoftmax_backward",
+           "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -110,6 +111,12 @@ def load() -> C.CDLL:
     lib.eec_ctc_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_logsoftmax_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.eec_frontend_last_error.restype = C.c_char_p
+    lib.eec_frontend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    lib.eec_frontend_destroy.argtypes = [C.c_void_p]
+    lib.eec_frontend_destroy.restype = None
+    lib.eec_frontend_frames.argtypes = [C.c_int, C.c_int]
+    lib.eec_frontend_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     _lib = lib

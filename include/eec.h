@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 8
+#define EEC_ABI_VERSION 9
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -219,6 +219,20 @@ int eec_ctc_loss_forward(const float* logp, const int64_t* targets, const int64_
 int eec_ctc_loss_backward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
                           int blank, const float* nll, void* bwd_workspace, const float* grad_loss, float* dlogp, void* stream);
 int eec_logsoftmax_backward(const float* logp, const float* grad_logp, int M, int V, float* grad_logits, void* stream);
+
+/* Mel front end: replaces util/data_loader.py:7-18 -- torchaudio Spectrogram(n_fft = 2 * args.n_fft = 1024,
+ * hop_length 160, win_length 320; hann window, power 2, centred frames with reflect padding) followed by MelScale(sample_rate,
+ * n_mels, n_stft = 513; htk scale, no normalisation), NO log -- on the device, as an exact-fp32 MFMA transform.
+ *   wave [B, Lmax] fp32; lengths_opt [B] int64 valid samples per utterance or NULL (all Lmax)
+ *   mel  [B, n_mels, 1 + Lmax / 160] fp32: utterance b fills its first 1 + lengths[b] / 160 frames (torch.stft, center=True),
+ *        the rest is zero -- what the reference's collate (pad_sequence with 0) hands to the model.
+ * The tables (window, DFT basis, filterbank) are built in eec_frontend_create; only the reference's geometry is served. */
+typedef struct eec_frontend eec_frontend;
+const char* eec_frontend_last_error(void);
+int eec_frontend_create(int sample_rate, int n_fft, int win_length, int hop_length, int n_mels, eec_frontend** out);
+void eec_frontend_destroy(eec_frontend* fe);
+int eec_frontend_frames(int n_samples, int hop_length);
+int eec_frontend_forward(eec_frontend* fe, const float* wave, const int64_t* lengths_opt, int B, int Lmax, float* mel, void* stream);
 
 #ifdef __cplusplus
 }

@@ -275,3 +275,23 @@ def test_oracle_conformer_layer_matches_independent_published_block():
         want = hf(x, attention_mask=add_mask)[0]
         got = mine(x.transpose(0, 1), pad).transpose(0, 1)
     assert (got - want).abs().max().item() < 2e-5
+
+
+def test_frontend_oracle_properties():
+    """oracle/frontend_ref.py (restated torchaudio Spectrogram + MelScale, util/data_loader.py:7-18): frame count, the
+    filterbank's shape / support, a pure tone lands in the right mel bin, batch padding semantics."""
+    from oracle import frontend_ref as FR
+    fb = FR.melscale_fbanks(513, 0.0, 8000.0, 80, 16000)
+    assert fb.shape == (513, 80) and (fb >= 0).all() and (fb.sum(0) > 0).all()
+    assert (fb > 0).sum().item() < 1200  # two slopes per bin
+    L = 16000
+    t = torch.arange(L) / 16000.0
+    wave = torch.sin(2 * torch.pi * 1000.0 * t)
+    mel = FR.mel_frontend(wave)
+    assert mel.shape == (80, 1 + L // 160)
+    hz = 700.0 * (10.0 ** (torch.linspace(0, 2595.0 * np.log10(1 + 8000 / 700.0), 82) / 2595.0) - 1.0)
+    peak = int(mel[:, 50].argmax())
+    assert hz[peak] <= 1000.0 <= hz[peak + 2]
+    batch = FR.mel_frontend_batch(torch.stack([wave, torch.cat([wave[:8000], torch.zeros(8000)])]), torch.tensor([16000, 8000]))
+    assert batch.shape == (2, 80, 101) and torch.equal(batch[0], mel) and (batch[1, :, 51:] == 0).all()
+    assert torch.allclose(batch[1, :, :51], FR.mel_frontend(wave[:8000]))
