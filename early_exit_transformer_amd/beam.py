@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from .model import greedy_ctc
+from .model import ctc_beam_decode, greedy_ctc
 
 
 class GreedyCTCDecoder(torch.nn.Module):
@@ -46,6 +46,15 @@ class BeamInference:
         self.args = args
 
     sequence_length_penalty = staticmethod(sequence_length_penalty)
+
+    def ctc_cuda_predict(self, emission: Tensor, tokens=None, beam_size: Optional[int] = None) -> List[List[int]]:
+        """util/beam_infer.py:102-112: beam-search hypotheses (token ids, nbest = 1) of one exit's log-probs
+        ``emission`` [B, T', V], input length T' for every utterance, beam ``args.beam_size``, blank_skip_threshold 0.95.
+        ``tokens`` (the token file the torchaudio decoder takes) is accepted and unused: ids are returned, blank = 0."""
+        beam = self._arg(beam_size, "beam_size")
+        tok, cnt, _ = ctc_beam_decode(emission, beam_size=beam, blank=0, blank_skip_threshold=0.95)
+        tok, cnt = tok.cpu(), cnt.cpu()
+        return [tok[b, : int(cnt[b])].tolist() for b in range(tok.size(0))]
 
     def _arg(self, value, name):
         if value is not None:

@@ -63,6 +63,7 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_encoder_forward_prefix", "eec_encoder_group_workspace_bytes", "eec_encoder_group_forward",
            "eec_encoder_head_forward", "eec_encoder_stem1_forward", "eec_encoder_lengths",
            "eec_ctc_backward_workspace_bytes", "eec_ctc_loss_forward", "eec_ctc_loss_backward", "eec_logsoftmax_backward",
+           "eec_ctc_beam_workspace_bytes", "eec_ctc_beam_decode",
            "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
@@ -111,6 +112,10 @@ def load() -> C.CDLL:
     lib.eec_ctc_loss_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_logsoftmax_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.eec_ctc_beam_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.eec_ctc_beam_workspace_bytes.restype = C.c_size_t
+    lib.eec_ctc_beam_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_frontend_last_error.restype = C.c_char_p
     lib.eec_frontend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.eec_frontend_destroy.argtypes = [C.c_void_p]

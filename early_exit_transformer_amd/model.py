@@ -507,6 +507,28 @@ def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
     return tokens, counts
 
 
+def ctc_beam_decode(logp: Tensor, beam_size: int = 10, blank: int = 0, blank_skip_threshold: float = 0.95):
+    """CTC prefix beam search of [N, T', V] log-probs on the device (eec_ctc_beam_decode): the best hypothesis per
+    sequence, as ``BeamInference.ctc_cuda_predict`` uses torchaudio's cuda_ctc_decoder (util/beam_infer.py:102-112).
+    Returns (tokens [N, T'] int32, counts [N] int32, scores [N] fp32)."""
+    if not logp.is_cuda:
+        raise RuntimeError("ctc_beam_decode runs on a HIP device only")
+    logp = logp.contiguous().float()
+    N, Tq, V = logp.shape
+    dev = logp.device
+    lib = capi.load()
+    tokens = torch.empty((N, Tq), dtype=torch.int32, device=dev)
+    counts = torch.empty((N,), dtype=torch.int32, device=dev)
+    scores = torch.empty((N,), dtype=torch.float32, device=dev)
+    ws = torch.empty((lib.eec_ctc_beam_workspace_bytes(N, Tq),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        capi.check(lib.eec_ctc_beam_decode(logp.data_ptr(), N, Tq, V, blank, beam_size, blank_skip_threshold, ws.data_ptr(),
+                                           tokens.data_ptr(), counts.data_ptr(), scores.data_ptr(), C.c_void_p(stream)),
+                   "eec_ctc_beam_decode")
+    return tokens, counts, scores
+
+
 def _ctc_prepare(enc_out: Tensor, targets: Tensor, target_len: Tensor):
     if not enc_out.is_cuda:
         raise RuntimeError("exit_ctc_losses runs on a HIP device only")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 9
+#define EEC_ABI_VERSION 10
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -219,6 +219,19 @@ int eec_ctc_loss_forward(const float* logp, const int64_t* targets, const int64_
 int eec_ctc_loss_backward(const float* logp, const int64_t* targets, const int64_t* target_len, int E, int B, int Tq, int V, int S,
                           int blank, const float* nll, void* bwd_workspace, const float* grad_loss, float* dlogp, void* stream);
 int eec_logsoftmax_backward(const float* logp, const float* grad_logp, int M, int V, float* grad_logits, void* stream);
+
+/* CTC prefix beam search: replaces BeamInference.ctc_cuda_predict (util/beam_infer.py:79-80,102-112:
+ * torchaudio cuda_ctc_decoder(tokens, nbest=1, beam_size=10, blank_skip_threshold=0.95) on the log-probs of one exit,
+ * input length T' for every utterance), batched over n_seq sequences.  That decoder is third-party CUDA code outside the
+ * reference tree: this is the published algorithm (prefix beam search without a language model; oracle/ctc_beam_ref.py),
+ * parity with torchaudio's tie-breaking is unpinned.
+ *   logp [n_seq, T', V] fp32 log-probs, blank label `blank` (0 in the reference), V <= 256, beam_size <= 16
+ *   blank_skip_threshold in (0, 1): a frame with p(blank) above it is taken as a blank frame without expansion; >= 1 disables
+ *   workspace: eec_ctc_beam_workspace_bytes(n_seq, T') bytes (back-pointers)
+ *   tokens [n_seq, T'] int32 (first counts[s] valid), counts [n_seq], scores [n_seq] = log p of the best prefix. */
+size_t eec_ctc_beam_workspace_bytes(int n_seq, int Tq);
+int eec_ctc_beam_decode(const float* logp, int n_seq, int Tq, int V, int blank, int beam_size, float blank_skip_threshold,
+                        void* workspace, int32_t* tokens, int32_t* counts, float* scores, void* stream);
 
 /* Mel front end: replaces util/data_loader.py:7-18 -- torchaudio Spectrogram(n_fft = 2 * args.n_fft = 1024,
  * hop_length 160, win_length 320; hann window, power 2, centred frames with reflect padding) followed by MelScale(sample_rate,

@@ -295,3 +295,30 @@ def test_frontend_oracle_properties():
     batch = FR.mel_frontend_batch(torch.stack([wave, torch.cat([wave[:8000], torch.zeros(8000)])]), torch.tensor([16000, 8000]))
     assert batch.shape == (2, 80, 101) and torch.equal(batch[0], mel) and (batch[1, :, 51:] == 0).all()
     assert torch.allclose(batch[1, :, :51], FR.mel_frontend(wave[:8000]))
+
+
+def test_ctc_beam_oracle_against_brute_force():
+    """oracle/ctc_beam_ref.py: with a beam wide enough to hold every prefix the search is exact -- the most probable
+    LABELLING (sum over all alignments), enumerated by brute force on tiny lattices; with blank-frame skipping off."""
+    import itertools
+    import math
+    from collections import defaultdict
+    from oracle.ctc_beam_ref import ctc_prefix_beam_search
+    rng = np.random.default_rng(0)
+    for T, V in ((5, 3), (6, 3), (4, 4)):
+        x = rng.standard_normal((T, V)) * 1.5
+        lp = x - np.log(np.exp(x).sum(-1, keepdims=True))
+        tot = defaultdict(float)
+        for path in itertools.product(range(V), repeat=T):
+            out, prev = [], -1
+            for c in path:
+                if c != prev and c != 0:
+                    out.append(c)
+                prev = c
+            tot[tuple(out)] += math.exp(sum(lp[t, c] for t, c in enumerate(path)))
+        best = max(tot, key=tot.get)
+        got, score = ctc_prefix_beam_search(lp, beam=200, blank_skip_threshold=1.0)
+        assert tuple(got) == best and abs(score - math.log(tot[best])) < 1e-9
+    # a repeated label across a skipped (blank) frame stays a repeat: "a <blank> a" -> [a, a]
+    lp = np.log(np.array([[0.01, 0.98, 0.01], [0.98, 0.01, 0.01], [0.01, 0.98, 0.01]]))
+    assert ctc_prefix_beam_search(lp, beam=4, blank_skip_threshold=0.95)[0] == [1, 1]
