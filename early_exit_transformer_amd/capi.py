@@ -64,7 +64,9 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_encoder_head_forward", "eec_encoder_stem1_forward", "eec_encoder_lengths",
            "eec_ctc_backward_workspace_bytes", "eec_ctc_loss_forward", "eec_ctc_loss_backward", "eec_logsoftmax_backward",
            "eec_ctc_beam_workspace_bytes", "eec_ctc_beam_decode",
-           "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward"]
+           "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward",
+           "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
+           "eec_train_forward", "eec_train_backward", "eec_train_gemm"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -122,6 +124,18 @@ def load() -> C.CDLL:
     lib.eec_frontend_destroy.restype = None
     lib.eec_frontend_frames.argtypes = [C.c_int, C.c_int]
     lib.eec_frontend_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.eec_trainer_last_error.restype = C.c_char_p
+    lib.eec_trainer_create.argtypes = [C.POINTER(EecConfig), C.POINTER(C.c_void_p)]
+    lib.eec_trainer_destroy.argtypes = [C.c_void_p]
+    lib.eec_trainer_destroy.restype = None
+    lib.eec_trainer_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.eec_trainer_workspace_bytes.restype = C.c_size_t
+    lib.eec_train_forward.argtypes = [C.c_void_p, C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_backward.argtypes = [C.c_void_p, C.POINTER(EecParams), C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p]
+    lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     _lib = lib

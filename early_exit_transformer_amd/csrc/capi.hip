@@ -244,7 +244,7 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
   };
   {
     ChainArgs ca{};
-    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = 1;
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = 1, ca.Tq = Tq;
     ca.st[0] = stage1(enc->layers[l0]);
     ca.qkv = qkv_args(enc->layers[l0]);
     TIMED(KC_CHAIN, launch_ffn_chain(ca, np.ffn, np.front, np.qkv, false, true, false, st));
@@ -263,7 +263,7 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
       TIMED(KC_PROJ_GLU, launch_proj_glu(pr, ga, np.glu, st));
     }
     ChainArgs ca{};
-    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = last ? 1 : 2;
+    ca.x = b.x, ca.M = M, ca.F = c.d_ff, ca.D = D, ca.nstage = last ? 1 : 2, ca.Tq = Tq;
     ca.dw = DwArgs{b.g, B, Tq, L.dw_wfold, L.dw_bfold, b.p_hi, b.p_lo};
     ca.pw2 = ProjResArgs{b.x, M, D, nullptr, nullptr, L.conv_pw2_p, L.conv_pw2_b, L.conv_pw2_f8};
     ca.st[0] = FfnStage{L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1p, L.ffn2_b1, L.ffn2_w2p, L.ffn2_b2, L.final_ln_w, L.final_ln_b,

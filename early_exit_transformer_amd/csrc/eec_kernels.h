@@ -124,6 +124,7 @@ struct FfnStage {
 struct ChainArgs {
   float* x;  // [M][D] residual stream, updated in place
   int M, F, nstage, D;
+  int Tq;  // frames per utterance (0: unknown); only the EEC_FFN_ROT == 2 chunk order reads it
   FfnStage st[2];
   QkvArgs qkv;      // tail (x / M of this block are ignored)
   DwArgs dw;        // front

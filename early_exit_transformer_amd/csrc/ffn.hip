@@ -231,7 +231,13 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
 #ifndef EEC_FFN_ROT
 #define EEC_FFN_ROT 0
 #endif
+#if EEC_FFN_ROT == 2
+  // rotation by the tile's position INSIDE its utterance (4 chunks per tile step): the summation order of a frame then
+  // depends on nothing but its own frame index, so results stay bit-identical under batch sharding / reordering
+  const int rot = ((nft & 3) == 0 && a.Tq > 0 && a.Tq % G::kRows == 0) ? (int)((unsigned)((row0 % a.Tq) / G::kRows * 4) % (unsigned)nchunk) : 0;
+#else
   const int rot = (EEC_FFN_ROT && (nft & 3) == 0) ? (int)((blockIdx.x >> 3) % (unsigned)nchunk) : 0;
+#endif
   auto phys = [&](int c) { const int p = c + rot; return p >= nchunk ? p - nchunk : p; };
   const size_t w2_nt_stride = (size_t)ks2_total * 128;
 

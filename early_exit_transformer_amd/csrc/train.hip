@@ -1,0 +1,531 @@
+// Training step of the Early_conformer path behind the C ABI (include/eec.h, eec_trainer_*): the forward in train mode
+// (batch-statistics BatchNorm, dropout at the reference's sites) that records what the backward needs, and the backward
+// that produces the gradient of every parameter -- what `enc_out = model(...)` / `loss.backward()` do in train.py:53-68.
+// Host code only; the kernels are in train_kernels.hip (+ the log-softmax backward of ctc.hip, the length kernel of pack.hip).
+//
+// Layer semantics follow torchaudio's ConformerLayer as restated in oracle/conformer_ref.py:
+//   x += 0.5 * drop(W2 . drop(silu(W1 . LN(x))));  x += drop(out_proj(MHA(LN(x), attention-prob dropout)));
+//   x += drop(pw2 . silu(BN_batch(dw(GLU(pw1 . LN(x))))));  x += 0.5 * ffn2(x);  x = LN(x)
+// stem: Conv1d(k3, s2) o Conv1d(k3, s2) (no activation), + positional encoding, dropout (early_exit.py:24-48, 617-623).
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/eec.h"
+#include "eec_kernels.h"
+#include "eec_train.h"
+
+using namespace eect;
+
+namespace {
+
+thread_local std::string g_terr;
+int tfail(int code, const std::string& msg) {
+  g_terr = msg;
+  return code;
+}
+
+struct Bump {  // bump allocator; base == nullptr: sizes only
+  char* base = nullptr;
+  size_t off = 0, peak = 0;
+  float* f(size_t n) {
+    off = (off + 255) / 256 * 256;
+    float* p = (float*)(base + off);
+    off += n * sizeof(float);
+    if (off > peak) peak = off;
+    return p;
+  }
+  void reset(size_t to = 0) { off = to; }
+};
+
+struct FfnTape {
+  float *x, *ln, *mean, *rstd, *pre;
+  uint32_t site_act, site_res;
+};
+struct AttnTape {
+  float *x, *ln, *mean, *rstd, *qkv, *P, *ctx;
+  uint32_t site_p, site_res;
+};
+struct ConvTape {
+  float *x, *ln, *mean, *rstd, *u, *g, *c, *stats, *s;
+  uint32_t site_res;
+};
+struct LayerTape {
+  FfnTape f1, f2;
+  AttnTape at;
+  ConvTape cv;
+  float *x4, *fmean, *frstd, *out;
+};
+
+}  // namespace
+
+struct eec_trainer {
+  eec_config cfg;
+  int device = 0;
+  // geometry / settings of the recorded forward
+  bool recorded = false;
+  int B = 0, T = 0, T1 = 0, Tq = 0, M = 0, np = 3;
+  float p = 0.0f;
+  uint64_t seed = 0;
+  std::vector<LayerTape> lt;
+  float *a1 = nullptr, *out1 = nullptr, *w2p = nullptr;
+  int32_t* key_len = nullptr;
+  uint32_t site_pe = 0;
+  size_t tape_bytes = 0;
+};
+
+namespace {
+
+struct Run {
+  eec_trainer* tr;
+  bool dry;
+  hipStream_t st;
+  Bump tape, scr;
+  hipError_t err = hipSuccess;
+  const char* where = "";
+  uint32_t site = 1;
+  void ok(hipError_t e, const char* w) {
+    if (e != hipSuccess && err == hipSuccess) err = e, where = w;
+  }
+};
+#define RUN(expr)                      \
+  do {                                 \
+    if (!r.dry) r.ok((expr), #expr);   \
+  } while (0)
+
+Drop drop_of(const Run& r, uint32_t site) { return Drop{r.tr->p, r.tr->seed, site}; }
+
+// y[M][N] = x[M][K] . W[N][K]^T + bias
+void linear_fwd(Run& r, const float* x, const float* W, const float* bias, float* y, int M, int N, int K) {
+  GemmArgs g = gemm_args(x, K, 1, W, K, 1, y, N, M, N, K);
+  g.bias = bias;
+  RUN(launch_gemm(g, r.tr->np, r.st));
+}
+// dx[M][K] (+)= dy[M][N] . W[N][K]
+void linear_bwd_data(Run& r, const float* dy, const float* W, float* dx, int M, int N, int K, bool accumulate = false) {
+  GemmArgs g = gemm_args(dy, N, 1, W, 1, K, dx, K, M, K, N);
+  g.accumulate = accumulate;
+  RUN(launch_gemm(g, r.tr->np, r.st));
+}
+// dW[N][K] = dy[M][N]^T . x[M][K] (split over the rows, partials summed in a fixed order); db[N] = column sums of dy
+void linear_bwd_weight(Run& r, const float* dy, const float* x, float* dW, float* db, int M, int N, int K) {
+  const size_t mark = r.scr.off;
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  int S = std::max(1, std::min(512 / tiles, M / 64));
+  int chunk = ((M + S - 1) / S + 31) / 32 * 32;
+  S = (M + chunk - 1) / chunk;
+  GemmArgs g = gemm_args(dy, 1, N, x, 1, K, dW, K, N, K, chunk);
+  if (S > 1) {
+    float* part = r.scr.f((size_t)S * N * K);
+    g.C = part, g.nz = S, g.zdiv = 1, g.ktot = M;
+    g.a_z0 = (long)chunk * N, g.b_z0 = (long)chunk * K, g.c_z0 = (long)N * K;
+    RUN(launch_gemm(g, r.tr->np, r.st));
+    RUN(launch_reduce_leading(part, S, (long)N * K, (long)N * K, dW, r.st));
+  } else {
+    g.K = M;
+    RUN(launch_gemm(g, r.tr->np, r.st));
+  }
+  if (db) {
+    const int nb = colsum_blocks(M);
+    float* part = r.scr.f((size_t)nb * N);
+    RUN(launch_colsum_partial(dy, M, N, part, r.st));
+    RUN(launch_reduce_leading(part, nb, N, N, db, r.st));
+  }
+  r.scr.reset(mark);
+}
+// dx = dx + LN'(dln) in place; dg / db from the per-block partials
+void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const float* mean, const float* rstd, float* dx, bool add_res, float* dg,
+            float* db, int M, int D) {
+  const size_t mark = r.scr.off;
+  const int nb = ln_bwd_blocks(M);
+  float* part = r.scr.f((size_t)nb * 2 * D);
+  RUN(launch_ln_bwd(dln, x, g, mean, rstd, add_res ? dx : nullptr, dx, part, M, D, r.st));
+  RUN(launch_reduce_leading(part, nb, 2 * D, D, dg, r.st));
+  RUN(launch_reduce_leading(part + D, nb, 2 * D, D, db, r.st));
+  r.scr.reset(mark);
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
+  const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
+  t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.pre = r.tape.f((size_t)M * F);
+  t.site_act = r.site++, t.site_res = r.site++;
+  RUN(launch_ln_fwd(x, ln_w, ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
+  linear_fwd(r, t.ln, w1, b1, t.pre, M, F, D);
+  r.scr.reset();
+  float* act = r.scr.f((size_t)M * F);
+  float* h = r.scr.f((size_t)M * D);
+  RUN(launch_silu_drop_fwd(t.pre, act, (long)M * F, drop_of(r, t.site_act), r.st));
+  linear_fwd(r, act, w2, b2, h, M, D, F);
+  float* y = r.tape.f((size_t)M * D);
+  RUN(launch_residual_drop_fwd(x, h, 0.5f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  return y;
+}
+
+// batched-GEMM strides of the attention operands: z = b * H + h
+struct AttnGeo {
+  int B, H, Tq, D, dh;
+  long qkv_b, qkv_h, p_b, p_h, x_b, x_h;
+};
+AttnGeo attn_geo(const eec_trainer* tr) {
+  AttnGeo a{tr->B, tr->cfg.n_heads, tr->Tq, tr->cfg.d_model, tr->cfg.d_model / tr->cfg.n_heads};
+  a.qkv_b = (long)a.Tq * 3 * a.D, a.qkv_h = a.dh;
+  a.p_b = (long)a.H * a.Tq * a.Tq, a.p_h = (long)a.Tq * a.Tq;
+  a.x_b = (long)a.Tq * a.D, a.x_h = a.dh;
+  return a;
+}
+void batched(GemmArgs& g, const AttnGeo& a, long az0, long az1, long bz0, long bz1, long cz0, long cz1) {
+  g.nz = a.B * a.H, g.zdiv = a.H;
+  g.a_z0 = az0, g.a_z1 = az1, g.b_z0 = bz0, g.b_z1 = bz1, g.c_z0 = cz0, g.c_z1 = cz1;
+}
+
+float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
+  const eec_trainer* tr = r.tr;
+  const AttnGeo a = attn_geo(tr);
+  const int M = tr->M, D = a.D, Tq = a.Tq;
+  t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.qkv = r.tape.f((size_t)M * 3 * D);
+  t.P = r.tape.f((size_t)a.B * a.H * Tq * Tq), t.ctx = r.tape.f((size_t)M * D);
+  t.site_p = r.site++, t.site_res = r.site++;
+  RUN(launch_ln_fwd(x, L.attn_ln_w, L.attn_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
+  linear_fwd(r, t.ln, L.attn_in_w, L.attn_in_b, t.qkv, M, 3 * D, D);
+  {  // S = Q . K^T
+    GemmArgs g = gemm_args(t.qkv, 3 * D, 1, t.qkv + D, 3 * D, 1, t.P, Tq, Tq, Tq, a.dh);
+    batched(g, a, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  RUN(launch_softmax_fwd(t.P, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), r.st));
+  r.scr.reset();
+  const float* Pd = t.P;
+  if (tr->p > 0.0f) {
+    float* pd = r.scr.f((size_t)a.B * a.H * Tq * Tq);
+    RUN(launch_drop_copy(t.P, pd, (long)a.B * a.H * Tq * Tq, drop_of(r, t.site_p), r.st));
+    Pd = pd;
+  }
+  {  // ctx = Pd . V
+    GemmArgs g = gemm_args(Pd, Tq, 1, t.qkv + 2 * D, 1, 3 * D, t.ctx, D, Tq, a.dh, Tq);
+    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.x_b, a.x_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  float* o = r.scr.f((size_t)M * D);
+  linear_fwd(r, t.ctx, L.attn_out_w, L.attn_out_b, o, M, D, D);
+  float* y = r.tape.f((size_t)M * D);
+  RUN(launch_residual_drop_fwd(x, o, 1.0f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  return y;
+}
+
+float* conv_fwd(Run& r, ConvTape& t, float* x, const eec_layer_params& L, float* bn_mv) {
+  const eec_trainer* tr = r.tr;
+  const int M = tr->M, D = tr->cfg.d_model, K = tr->cfg.dw_kernel;
+  t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.u = r.tape.f((size_t)M * 2 * D);
+  t.g = r.tape.f((size_t)M * D), t.c = r.tape.f((size_t)M * D), t.stats = r.tape.f(2 * D), t.s = r.tape.f((size_t)M * D);
+  t.site_res = r.site++;
+  RUN(launch_ln_fwd(x, L.conv_ln_w, L.conv_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
+  linear_fwd(r, t.ln, L.conv_pw1_w, L.conv_pw1_b, t.u, M, 2 * D, D);
+  RUN(launch_glu_fwd(t.u, t.g, M, D, r.st));
+  RUN(launch_dw_fwd(t.g, L.conv_dw_w, L.conv_dw_b, t.c, tr->B, tr->Tq, D, K, r.st));
+  r.scr.reset();
+  float* part = r.scr.f((size_t)colsum_blocks(M) * 2 * D);
+  RUN(launch_bn_stats(t.c, M, D, part, t.stats, bn_mv, r.st));
+  RUN(launch_bn_silu_fwd(t.c, t.stats, L.conv_bn_w, L.conv_bn_b, t.s, M, D, r.st));
+  float* v = r.scr.f((size_t)M * D);
+  linear_fwd(r, t.s, L.conv_pw2_w, L.conv_pw2_b, v, M, D, D);
+  float* y = r.tape.f((size_t)M * D);
+  RUN(launch_residual_drop_fwd(x, v, 1.0f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  return y;
+}
+
+void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengths, float* out, float* bn_mv) {
+  eec_trainer* tr = r.tr;
+  const eec_config& c = tr->cfg;
+  const int B = tr->B, T = tr->T, T1 = tr->T1, Tq = tr->Tq, M = tr->M, D = c.d_model, C = c.n_mels, V = c.vocab;
+  const int nl = c.n_exits * c.layers_per_exit;
+  tr->lt.assign(nl, LayerTape{});
+  tr->key_len = (int32_t*)r.tape.f(B);
+  tr->a1 = r.tape.f((size_t)B * T1 * 3 * C), tr->out1 = r.tape.f((size_t)B * T1 * D), tr->w2p = r.tape.f((size_t)D * 3 * D);
+  float* x = r.tape.f((size_t)M * D);
+  tr->site_pe = r.site++;
+  RUN(eec::launch_enc_lengths((const long long*)lengths, B, Tq, tr->key_len, r.st));
+  RUN(launch_im2col_mel(mel, tr->a1, B, C, T, T1, r.st));
+  linear_fwd(r, tr->a1, P->sub0_w, P->sub0_b, tr->out1, B * T1, D, 3 * C);
+  RUN(launch_permute_w3(P->sub1_w, tr->w2p, D, D, 1, r.st));
+  {  // second conv: three consecutive rows of out1 are one contiguous K = 3D operand row
+    GemmArgs g = gemm_args(tr->out1, 2 * D, 1, tr->w2p, 3 * D, 1, x, D, Tq, D, 3 * D);
+    g.bias = P->sub1_b, g.nz = B, g.zdiv = 1, g.a_z0 = (long)T1 * D, g.c_z0 = (long)Tq * D;
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  RUN(launch_add_pe_drop(x, P->pe, B, Tq, D, drop_of(r, tr->site_pe), r.st));
+  for (int e = 0; e < c.n_exits; ++e) {
+    for (int l = 0; l < c.layers_per_exit; ++l) {
+      const int li = e * c.layers_per_exit + l;
+      const eec_layer_params& L = P->layers[li];
+      LayerTape& t = tr->lt[li];
+      x = ffn_fwd(r, t.f1, x, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1, L.ffn1_b1, L.ffn1_w2, L.ffn1_b2);
+      x = attn_fwd(r, t.at, x, L);
+      x = conv_fwd(r, t.cv, x, L, bn_mv ? bn_mv + (size_t)li * 2 * D : nullptr);
+      x = ffn_fwd(r, t.f2, x, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1, L.ffn2_b1, L.ffn2_w2, L.ffn2_b2);
+      t.x4 = x, t.fmean = r.tape.f(M), t.frstd = r.tape.f(M), t.out = r.tape.f((size_t)M * D);
+      RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
+      x = t.out;
+    }
+    r.scr.reset();
+    float* logits = r.scr.f((size_t)M * V);
+    linear_fwd(r, x, P->head_w[e], P->head_b[e], logits, M, V, D);
+    RUN(launch_logsoftmax_fwd(logits, out + (size_t)e * M * V, M, V, r.st));
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------------------------------
+void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float* w1, const float* w2, float* g_ln_w, float* g_ln_b, float* g_w1,
+             float* g_b1, float* g_w2, float* g_b2) {
+  const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
+  r.scr.reset();
+  float* dh = r.scr.f((size_t)M * D);
+  float* act = r.scr.f((size_t)M * F);
+  float* dact = r.scr.f((size_t)M * F);
+  RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
+  RUN(launch_silu_drop_fwd(t.pre, act, (long)M * F, drop_of(r, t.site_act), r.st));
+  linear_bwd_weight(r, dh, act, g_w2, g_b2, M, D, F);
+  linear_bwd_data(r, dh, w2, dact, M, D, F);
+  RUN(launch_silu_drop_bwd(dact, t.pre, dact, (long)M * F, drop_of(r, t.site_act), r.st));
+  linear_bwd_weight(r, dact, t.ln, g_w1, g_b1, M, F, D);
+  linear_bwd_data(r, dact, w1, dh, M, F, D);  // dh now holds d LN-output
+  ln_bwd(r, dh, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
+}
+
+void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, eec_layer_params& G) {
+  const eec_trainer* tr = r.tr;
+  const AttnGeo a = attn_geo(tr);
+  const int M = tr->M, D = a.D, Tq = a.Tq;
+  const long np_ = (long)a.B * a.H * Tq * Tq;
+  r.scr.reset();
+  float* d_o = r.scr.f((size_t)M * D);
+  float* dctx = r.scr.f((size_t)M * D);
+  float* dqkv = r.scr.f((size_t)M * 3 * D);
+  float* dP = r.scr.f((size_t)np_);
+  RUN(launch_scale_drop(dx, 1.0f, d_o, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_bwd_weight(r, d_o, t.ctx, (float*)G.attn_out_w, (float*)G.attn_out_b, M, D, D);
+  linear_bwd_data(r, d_o, L.attn_out_w, dctx, M, D, D);
+  const float* Pd = t.P;
+  if (tr->p > 0.0f) {
+    float* pd = r.scr.f((size_t)np_);
+    RUN(launch_drop_copy(t.P, pd, np_, drop_of(r, t.site_p), r.st));
+    Pd = pd;
+  }
+  {  // dV[tk][d] = sum_tq Pd[tq][tk] dctx[tq][d]
+    GemmArgs g = gemm_args(Pd, 1, Tq, dctx, 1, D, dqkv + 2 * D, 3 * D, Tq, a.dh, Tq);
+    batched(g, a, a.p_b, a.p_h, a.x_b, a.x_h, a.qkv_b, a.qkv_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  {  // dPd[tq][tk] = sum_d dctx[tq][d] V[tk][d]
+    GemmArgs g = gemm_args(dctx, D, 1, t.qkv + 2 * D, 3 * D, 1, dP, Tq, Tq, Tq, a.dh);
+    batched(g, a, a.x_b, a.x_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  RUN(launch_softmax_bwd(t.P, dP, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
+  {  // dQ[tq][d] = sum_tk dS[tq][tk] K[tk][d]
+    GemmArgs g = gemm_args(dP, Tq, 1, t.qkv + D, 1, 3 * D, dqkv, 3 * D, Tq, a.dh, Tq);
+    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  {  // dK[tk][d] = sum_tq dS[tq][tk] Q[tq][d]
+    GemmArgs g = gemm_args(dP, 1, Tq, t.qkv, 1, 3 * D, dqkv + D, 3 * D, Tq, a.dh, Tq);
+    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  linear_bwd_weight(r, dqkv, t.ln, (float*)G.attn_in_w, (float*)G.attn_in_b, M, 3 * D, D);
+  linear_bwd_data(r, dqkv, L.attn_in_w, d_o, M, 3 * D, D);  // d_o now holds d LN-output
+  ln_bwd(r, d_o, t.x, L.attn_ln_w, t.mean, t.rstd, dx, true, (float*)G.attn_ln_w, (float*)G.attn_ln_b, M, D);
+}
+
+void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, eec_layer_params& G) {
+  const eec_trainer* tr = r.tr;
+  const int M = tr->M, D = tr->cfg.d_model, K = tr->cfg.dw_kernel;
+  r.scr.reset();
+  float* dv = r.scr.f((size_t)M * D);
+  float* ds = r.scr.f((size_t)M * D);
+  float* dc = r.scr.f((size_t)M * D);
+  float* du = r.scr.f((size_t)M * 2 * D);
+  float* sums = r.scr.f(2 * D);
+  RUN(launch_scale_drop(dx, 1.0f, dv, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_bwd_weight(r, dv, t.s, (float*)G.conv_pw2_w, (float*)G.conv_pw2_b, M, D, D);
+  linear_bwd_data(r, dv, L.conv_pw2_w, ds, M, D, D);
+  {
+    const size_t mark = r.scr.off;
+    float* part = r.scr.f((size_t)colsum_blocks(M) * 2 * D);
+    RUN(launch_bn_silu_bwd(ds, t.c, t.stats, L.conv_bn_w, L.conv_bn_b, part, sums, dc, M, D, r.st));
+    RUN(hipMemcpyAsync((void*)G.conv_bn_b, sums, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+    RUN(hipMemcpyAsync((void*)G.conv_bn_w, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+    r.scr.reset(mark);
+    float* wpart = r.scr.f((size_t)dw_bwd_weight_blocks(tr->B, tr->Tq) * (K + 1) * D);
+    RUN(launch_dw_bwd_weight(dc, t.g, wpart, (float*)G.conv_dw_w, (float*)G.conv_dw_b, tr->B, tr->Tq, D, K, r.st));
+    r.scr.reset(mark);
+  }
+  RUN(launch_dw_bwd_data(dc, L.conv_dw_w, ds, tr->B, tr->Tq, D, K, r.st));  // ds now holds d GLU-output
+  RUN(launch_glu_bwd(ds, t.u, du, M, D, r.st));
+  linear_bwd_weight(r, du, t.ln, (float*)G.conv_pw1_w, (float*)G.conv_pw1_b, M, 2 * D, D);
+  linear_bwd_data(r, du, L.conv_pw1_w, dv, M, 2 * D, D);  // dv now holds d LN-output
+  ln_bwd(r, dv, t.x, L.conv_ln_w, t.mean, t.rstd, dx, true, (float*)G.conv_ln_w, (float*)G.conv_ln_b, M, D);
+}
+
+void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out) {
+  eec_trainer* tr = r.tr;
+  const eec_config& c = tr->cfg;
+  const int B = tr->B, T1 = tr->T1, Tq = tr->Tq, M = tr->M, D = c.d_model, C = c.n_mels, V = c.vocab;
+  // the gradient of the residual stream lives at the start of the scratch region for the whole backward
+  float* dx = r.tape.f((size_t)M * D);
+  for (int e = c.n_exits - 1; e >= 0; --e) {
+    const float* tap = tr->lt[(e + 1) * c.layers_per_exit - 1].out;
+    r.scr.reset();
+    float* dlogits = r.scr.f((size_t)M * V);
+    RUN(eec::launch_logsoftmax_backward(out + (size_t)e * M * V, grad_out + (size_t)e * M * V, M, V, dlogits, r.st));
+    linear_bwd_weight(r, dlogits, tap, (float*)Gp->head_w[e], (float*)Gp->head_b[e], M, V, D);
+    linear_bwd_data(r, dlogits, P->head_w[e], dx, M, V, D, e != c.n_exits - 1);
+    for (int l = c.layers_per_exit - 1; l >= 0; --l) {
+      const int li = e * c.layers_per_exit + l;
+      const eec_layer_params& L = P->layers[li];
+      eec_layer_params G = Gp->layers[li];
+      const LayerTape& t = tr->lt[li];
+      ln_bwd(r, dx, t.x4, L.final_ln_w, t.fmean, t.frstd, dx, false, (float*)G.final_ln_w, (float*)G.final_ln_b, M, D);
+      ffn_bwd(r, t.f2, dx, L.ffn2_ln_w, L.ffn2_w1, L.ffn2_w2, (float*)G.ffn2_ln_w, (float*)G.ffn2_ln_b, (float*)G.ffn2_w1, (float*)G.ffn2_b1,
+              (float*)G.ffn2_w2, (float*)G.ffn2_b2);
+      conv_bwd(r, t.cv, dx, L, G);
+      attn_bwd(r, t.at, dx, L, G);
+      ffn_bwd(r, t.f1, dx, L.ffn1_ln_w, L.ffn1_w1, L.ffn1_w2, (float*)G.ffn1_ln_w, (float*)G.ffn1_ln_b, (float*)G.ffn1_w1, (float*)G.ffn1_b1,
+              (float*)G.ffn1_w2, (float*)G.ffn1_b2);
+    }
+  }
+  // stem
+  r.scr.reset();
+  float* dx0 = r.scr.f((size_t)M * D);
+  float* Gc = r.scr.f((size_t)M * 3 * D);
+  float* dout1 = r.scr.f((size_t)B * T1 * D);
+  float* dw2p = r.scr.f((size_t)D * 3 * D);
+  RUN(launch_scale_drop(dx, 1.0f, dx0, (long)M * D, drop_of(r, tr->site_pe), r.st));
+  {
+    const size_t mark = r.scr.off;
+    float* part = r.scr.f((size_t)B * D * 3 * D);
+    GemmArgs g = gemm_args(dx0, 1, D, tr->out1, 1, 2 * D, part, 3 * D, D, 3 * D, Tq);
+    g.nz = B, g.zdiv = 1, g.a_z0 = (long)Tq * D, g.b_z0 = (long)T1 * D, g.c_z0 = (long)D * 3 * D;
+    RUN(launch_gemm(g, tr->np, r.st));
+    RUN(launch_reduce_leading(part, B, (long)D * 3 * D, (long)D * 3 * D, dw2p, r.st));
+    RUN(launch_permute_w3(dw2p, (float*)Gp->sub1_w, D, D, 0, r.st));
+    r.scr.reset(mark);
+    const int nb = colsum_blocks(M);
+    float* bpart = r.scr.f((size_t)nb * D);
+    RUN(launch_colsum_partial(dx0, M, D, bpart, r.st));
+    RUN(launch_reduce_leading(bpart, nb, D, D, (float*)Gp->sub1_b, r.st));
+    r.scr.reset(mark);
+  }
+  {  // G[m][(j, c)] = sum_o dx0[m][o] w2p[o][(j, c)]
+    GemmArgs g = gemm_args(dx0, D, 1, tr->w2p, 1, 3 * D, Gc, 3 * D, M, 3 * D, D);
+    RUN(launch_gemm(g, tr->np, r.st));
+  }
+  RUN(launch_col2im_stride2(Gc, dout1, B, T1, Tq, D, r.st));
+  linear_bwd_weight(r, dout1, tr->a1, (float*)Gp->sub0_w, (float*)Gp->sub0_b, B * T1, D, 3 * C);
+}
+
+int check_trainer_cfg(const eec_config& c) {
+  if (c.arch != EEC_ARCH_CONFORMER) return tfail(EEC_ERR_UNSUPPORTED, "the training step covers the Conformer architecture");
+  if (c.d_model <= 0 || c.d_model > 1024 || c.n_heads <= 0 || c.d_model % c.n_heads) return tfail(EEC_ERR_BAD_ARG, "d_model <= 1024, divisible by n_heads");
+  if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1)) return tfail(EEC_ERR_BAD_ARG, "depthwise kernel: odd, <= 31");
+  if (c.d_ff <= 0 || c.n_exits <= 0 || c.layers_per_exit <= 0 || c.n_mels <= 0 || c.vocab <= 0 || c.vocab > 1024) return tfail(EEC_ERR_BAD_ARG, "bad configuration");
+  return 0;
+}
+
+int set_geometry(eec_trainer* tr, int B, int T) {
+  if (B <= 0 || T < 7) return tfail(EEC_ERR_BAD_ARG, "B >= 1, T >= 7");
+  tr->B = B, tr->T = T, tr->T1 = (T - 3) / 2 + 1, tr->Tq = (tr->T1 - 3) / 2 + 1, tr->M = B * tr->Tq;
+  if (tr->Tq > tr->cfg.max_len) return tfail(EEC_ERR_BAD_ARG, "T' exceeds max_len");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* eec_trainer_last_error(void) { return g_terr.c_str(); }
+
+int eec_trainer_create(const eec_config* cfg, eec_trainer** out) {
+  if (!cfg || !out) return tfail(EEC_ERR_BAD_ARG, "null argument");
+  if (int rc = check_trainer_cfg(*cfg)) return rc;
+  eec_trainer* tr = new eec_trainer();
+  tr->cfg = *cfg;
+  if (hipError_t e = hipGetDevice(&tr->device); e != hipSuccess) {
+    delete tr;
+    return tfail((int)e, std::string("hipGetDevice: ") + hipGetErrorString(e));
+  }
+  *out = tr;
+  return 0;
+}
+void eec_trainer_destroy(eec_trainer* tr) { delete tr; }
+
+size_t eec_trainer_workspace_bytes(const eec_trainer* tr_in, int B, int T) {
+  if (!tr_in) return 0;
+  eec_trainer tmp = *tr_in;
+  if (set_geometry(&tmp, B, T)) return 0;
+  tmp.p = 0.5f;  // sizes the dropped-probability copies too
+  Run r{&tmp, true, nullptr};
+  std::vector<eec_layer_params> layers(tmp.cfg.n_exits * tmp.cfg.layers_per_exit);
+  std::vector<const float*> heads(tmp.cfg.n_exits, nullptr);
+  eec_params P{};
+  P.layers = layers.data(), P.head_w = heads.data(), P.head_b = heads.data();
+  forward(r, &P, nullptr, nullptr, nullptr, nullptr);
+  const size_t fwd_scr = r.scr.peak;
+  r.scr = Bump{};
+  backward(r, &P, &P, nullptr, nullptr);
+  return (r.tape.peak + 256) + std::max(fwd_scr, r.scr.peak) + 4096;
+}
+
+int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* mel, const int64_t* lengths, int B, int T, int passes,
+                      float drop_prob, uint64_t seed, float* out, float* bn_batch_stats, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!tr || !params || !mel || !lengths || !out || !workspace) return tfail(EEC_ERR_BAD_ARG, "null argument");
+  if (passes != 1 && passes != 3) return tfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
+  if (!(drop_prob >= 0.0f && drop_prob < 1.0f)) return tfail(EEC_ERR_BAD_ARG, "drop_prob in [0, 1)");
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != tr->device) return tfail(EEC_ERR_BAD_ARG, "the trainer belongs to another device");
+  if (int rc = set_geometry(tr, B, T)) return rc;
+  if (workspace_bytes < eec_trainer_workspace_bytes(tr, B, T)) return tfail(EEC_ERR_BAD_ARG, "workspace too small");
+  tr->np = passes, tr->p = drop_prob, tr->seed = seed, tr->recorded = false;
+  Run r{tr, false, (hipStream_t)stream};
+  r.tape.base = (char*)workspace;
+  // forward once with a null scratch to learn where the tape ends (pointer arithmetic only), then for real
+  {
+    eec_trainer tmp = *tr;
+    Run d{&tmp, true, nullptr};
+    forward(d, params, mel, lengths, out, bn_batch_stats);
+    tr->tape_bytes = (d.tape.peak + 255) / 256 * 256;
+  }
+  r.scr.base = (char*)workspace + tr->tape_bytes;
+  forward(r, params, mel, lengths, out, bn_batch_stats);
+  if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
+  tr->recorded = true;
+  return 0;
+}
+
+int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  if (!tr || !params || !grads || !out || !grad_out || !workspace) return tfail(EEC_ERR_BAD_ARG, "null argument");
+  if (!tr->recorded) return tfail(EEC_ERR_BAD_ARG, "no recorded forward (eec_train_forward first, same workspace)");
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev != tr->device) return tfail(EEC_ERR_BAD_ARG, "the trainer belongs to another device");
+  if (workspace_bytes < eec_trainer_workspace_bytes(tr, tr->B, tr->T)) return tfail(EEC_ERR_BAD_ARG, "workspace too small");
+  Run r{tr, false, (hipStream_t)stream};
+  // the residual-stream gradient is carved from the head of the scratch region through `tape` (kept for the whole backward)
+  r.tape.base = (char*)workspace + tr->tape_bytes;
+  r.scr.base = (char*)workspace + tr->tape_bytes + ((size_t)tr->M * tr->cfg.d_model * sizeof(float) + 511) / 256 * 256;
+  backward(r, params, grads, out, grad_out);
+  if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
+  return 0;
+}
+
+int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
+                   int b_transposed, void* stream) {
+  if (!A || !B || !C || (passes != 1 && passes != 3)) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  // a_transposed: A is stored [K][M]; b_transposed: B is stored [K][N]
+  GemmArgs g = gemm_args(A, a_transposed ? 1 : K, a_transposed ? M : 1, B, b_transposed ? 1 : K, b_transposed ? N : 1, C, N, M, N, K);
+  g.bias = bias;
+  if (hipError_t e = launch_gemm(g, passes, (hipStream_t)stream); e != hipSuccess) return tfail((int)e, hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,695 @@
+// Kernels of the training step (see eec_train.h): one general bf16-split MFMA GEMM and the row / column / pointwise
+// kernels around it.  fp32 in HBM everywhere; nothing here is shared with the fused inference path.
+#include "eec_train.h"
+
+namespace eect {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kBK = 32;   // k extent of one LDS tile
+constexpr int kLdk = 40;  // bf16 elements per LDS tile row (80 B: the 16 lanes of a ds_read_b128 group cover all 64 banks once)
+
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dropout
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool drop_keep(const Drop& d, uint64_t i, uint32_t thr) {
+  uint64_t x = i + d.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)d.site << 44);
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32) >= thr;
+}
+__device__ __forceinline__ uint32_t drop_thr(float p) {
+  const double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+// multiplier of element i under dropout d (1 when p == 0)
+__device__ __forceinline__ float drop_mul(const Drop& d, uint64_t i, uint32_t thr, float inv_keep) {
+  if (d.p <= 0.0f) return 1.0f;
+  return drop_keep(d, i, thr) ? inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load4(float (&v)[4], const float* p, long step, int nv) {
+  if (nv == 4 && step == 1 && (((uintptr_t)p) & 15) == 0) {
+    const f32x4 q = *(const f32x4*)p;
+    v[0] = q[0], v[1] = q[1], v[2] = q[2], v[3] = q[3];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = j < nv ? p[j * step] : 0.0f;
+  }
+}
+
+// R x 32 tile of an operand X(r, k) = X[s_r * r + s_k * k] into registers: 4 consecutive elements along the unit-stride axis
+template <int R>
+__device__ __forceinline__ void load_tile(float (&reg)[R / 32][4], const float* __restrict__ X, long s_r, long s_k, int r0, int k0,
+                                          int Rmax, int K, bool kc, int tid) {
+#pragma unroll
+  for (int it = 0; it < R / 32; ++it) {
+    const int idx = it * 256 + tid;
+    if (kc) {
+      const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+      const int nv = r < Rmax ? min(max(K - k, 0), 4) : 0;
+      load4(reg[it], X + (long)r * s_r + k, 1, nv);
+    } else {
+      const int r = r0 + (idx % (R / 4)) * 4, k = k0 + idx / (R / 4);
+      const int nv = k < K ? min(max(Rmax - r, 0), 4) : 0;
+      load4(reg[it], X + (long)k * s_k + r, 1, nv);
+    }
+  }
+}
+template <int R, int NP>
+__device__ __forceinline__ void store_tile(bf16* __restrict__ hi, bf16* __restrict__ lo, const float (&reg)[R / 32][4], bool kc, int tid) {
+#pragma unroll
+  for (int it = 0; it < R / 32; ++it) {
+    const int idx = it * 256 + tid;
+    const f32x4 x = {reg[it][0], reg[it][1], reg[it][2], reg[it][3]};
+    const bf16x4 h = __builtin_convertvector(x, bf16x4);
+    bf16x4 l;
+    if (NP == 3) l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
+    if (kc) {
+      const int r = idx >> 3, k = (idx & 7) * 4;
+      *(bf16x4*)(hi + r * kLdk + k) = h;
+      if (NP == 3) *(bf16x4*)(lo + r * kLdk + k) = l;
+    } else {
+      const int r = (idx % (R / 4)) * 4, k = idx / (R / 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[(r + j) * kLdk + k] = h[j];
+        if (NP == 3) lo[(r + j) * kLdk + k] = l[j];
+      }
+    }
+  }
+}
+
+template <int TM, int TN, int WGM, int WGN, int NP>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  static_assert(WGM * WGN == 4, "4 waves");
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  __shared__ __attribute__((aligned(16))) bf16 a_hi[BM * kLdk];
+  __shared__ __attribute__((aligned(16))) bf16 a_lo[NP == 3 ? BM * kLdk : 8];
+  __shared__ __attribute__((aligned(16))) bf16 b_hi[BN * kLdk];
+  __shared__ __attribute__((aligned(16))) bf16 b_lo[NP == 3 ? BN * kLdk : 8];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
+  const int z0 = blockIdx.z / g.zdiv, z1 = blockIdx.z % g.zdiv;
+  const float* __restrict__ A = g.A + z0 * g.a_z0 + z1 * g.a_z1;
+  const float* __restrict__ B = g.B + z0 * g.b_z0 + z1 * g.b_z1;
+  float* __restrict__ C = g.C + z0 * g.c_z0 + z1 * g.c_z1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const bool a_kc = g.a_k == 1, b_kc = g.b_k == 1;
+  const long a_r = a_kc ? g.a_m : 1, a_s = a_kc ? 1 : g.a_k;  // (row stride, k stride) as load_tile wants them
+  const long b_r = b_kc ? g.b_n : 1, b_s = b_kc ? 1 : g.b_k;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+  float ra[BM / 32][4], rb[BN / 32][4];
+  const int K = g.ktot > 0 ? min(g.K, g.ktot - z0 * g.K) : g.K;
+  const int nk = (K + kBK - 1) / kBK;
+  load_tile<BM>(ra, A, a_r, a_s, m0, 0, g.M, K, a_kc, tid);
+  load_tile<BN>(rb, B, b_r, b_s, n0, 0, g.N, K, b_kc, tid);
+  for (int kt = 0; kt < nk; ++kt) {
+    store_tile<BM, NP>(a_hi, a_lo, ra, a_kc, tid);
+    store_tile<BN, NP>(b_hi, b_lo, rb, b_kc, tid);
+    __syncthreads();
+    if (kt + 1 < nk) {
+      load_tile<BM>(ra, A, a_r, a_s, m0, (kt + 1) * kBK, g.M, K, a_kc, tid);
+      load_tile<BN>(rb, B, b_r, b_s, n0, (kt + 1) * kBK, g.N, K, b_kc, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      const int ko = ks * 16 + (lane >> 5) * 8;
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt) {
+        const int r = (wm * TM + mt) * 32 + (lane & 31);
+        ah[mt] = *(const bf16x8*)(a_hi + r * kLdk + ko);
+        if (NP == 3) al[mt] = *(const bf16x8*)(a_lo + r * kLdk + ko);
+      }
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int r = (wn * TN + nt) * 32 + (lane & 31);
+        bh[nt] = *(const bf16x8*)(b_hi + r * kLdk + ko);
+        if (NP == 3) bl[nt] = *(const bf16x8*)(b_lo + r * kLdk + ko);
+      }
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          if (NP == 3) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) {
+      const int n = n0 + (wn * TN + nt) * 32 + (lane & 31);
+      if (n >= g.N) continue;
+      const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = m0 + (wm * TM + mt) * 32 + acc_row(i, lane);
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[mt][nt][i] + bias;
+        float* p = C + (long)m * g.c_m + n;
+        if (g.accumulate) v += *p;
+        *p = v;
+      }
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN>
+static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nz);
+  if (np == 1) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, 1>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, 3>), grid, dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nz <= 0) return hipSuccess;
+  if ((g.a_m != 1 && g.a_k != 1) || (g.b_n != 1 && g.b_k != 1)) return hipErrorInvalidValue;
+  if (g.N <= 32) return launch_gemm_t<1, 1, 4, 1>(g, np, st);  // 128 x 32 tiles
+  if (g.N <= 64) return launch_gemm_t<2, 1, 2, 2>(g, np, st);  // 128 x 64
+  return launch_gemm_t<2, 2, 2, 2>(g, np, st);                 // 128 x 128
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LayerNorm
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLnMax = 16;  // elements per lane: D <= 1024
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                     float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * D;
+  float v[kLnMax], s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c < D ? xr[c] : 0.0f;
+    s += v[i];
+  }
+  const float mu = wave_sum(s) / D;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    const float d = c < D ? v[i] - mu : 0.0f;
+    q += d * d;
+  }
+  const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    if (c < D) y[(long)row * D + c] = (v[i] - mu) * rs * g[c] + b[c];
+  }
+  if (lane == 0) mean[row] = mu, rstd[row] = rs;
+}
+hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, int D, hipStream_t st) {
+  if (D > 64 * kLnMax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, y, mean, rstd, M, D);
+  return hipGetLastError();
+}
+
+int ln_bwd_blocks(int M) { return max(1, min(256, (M + 15) / 16)); }
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ part, int M, int D) {
+  __shared__ float red[4][2][64 * kLnMax];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
+  float gam[kLnMax], dg[kLnMax], db[kLnMax];
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) {
+    const int c = lane + 64 * i;
+    gam[i] = c < D ? g[c] : 0.0f, dg[i] = 0.0f, db[i] = 0.0f;
+  }
+  for (int row = r_begin + w; row < r_end; row += 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[kLnMax], dyv[kLnMax], c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < kLnMax; ++i) {
+      const int c = lane + 64 * i;
+      const bool ok = c < D;
+      xh[i] = ok ? (x[(long)row * D + c] - mu) * rs : 0.0f;
+      dyv[i] = ok ? dy[(long)row * D + c] : 0.0f;
+      const float t = dyv[i] * gam[i];
+      c1 += t, c2 += t * xh[i];
+      dg[i] += dyv[i] * xh[i], db[i] += dyv[i];
+    }
+    c1 = wave_sum(c1) / D, c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int i = 0; i < kLnMax; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) {
+        float v = rs * (dyv[i] * gam[i] - c1 - xh[i] * c2);
+        if (dres) v += dres[(long)row * D + c];
+        dx[(long)row * D + c] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < kLnMax; ++i) red[w][0][lane + 64 * i] = dg[i], red[w][1][lane + 64 * i] = db[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    part[((long)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    part[((long)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* dres,
+                         float* dx, float* part, int M, int D, hipStream_t st) {
+  if (D > 64 * kLnMax) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(M)), dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void reduce_leading_kernel(const float* __restrict__ part, int S, long stride, long n, float* __restrict__ out) {
+  const long j = (long)blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  float s = 0.0f;
+  for (int i = 0; i < S; ++i) s += part[(long)i * stride + j];
+  out[j] = s;
+}
+hipError_t launch_reduce_leading(const float* part, int S, long stride, long n, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(reduce_leading_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, stride, n, out);
+  return hipGetLastError();
+}
+
+int colsum_blocks(int M) { return max(1, min(512, (M + 31) / 32)); }
+// part[blk][which][n]: which = 0: sum of (x - shift), 1 (only if SQ): sum of (x - shift)^2
+template <bool SQ>
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int M, int N, const float* __restrict__ shift, float* __restrict__ part) {
+  const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float sh = shift ? shift[c] : 0.0f;
+    float s = 0.0f, q = 0.0f;
+    for (int r = r_begin; r < r_end; ++r) {
+      const float v = X[(long)r * N + c] - sh;
+      s += v;
+      if (SQ) q += v * v;
+    }
+    if (SQ) part[((long)blockIdx.x * 2) * N + c] = s, part[((long)blockIdx.x * 2 + 1) * N + c] = q;
+    else part[(long)blockIdx.x * N + c] = s;
+  }
+}
+hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_kernel<false>, dim3(colsum_blocks(M)), dim3(256), 0, st, X, M, N, (const float*)nullptr, part);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pointwise
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__global__ __launch_bounds__(256) void silu_drop_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = pre[i];
+    act[i] = x * sigmoidf_(x) * drop_mul(d, (uint64_t)i, thr, ik);
+  }
+}
+__global__ __launch_bounds__(256) void silu_drop_bwd_kernel(const float* __restrict__ dact, const float* __restrict__ pre, float* __restrict__ dpre, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = pre[i], s = sigmoidf_(x);
+    dpre[i] = dact[i] * drop_mul(d, (uint64_t)i, thr, ik) * s * (1.0f + x * (1.0f - s));
+  }
+}
+__global__ __launch_bounds__(256) void residual_drop_fwd_kernel(const float* __restrict__ r, const float* __restrict__ h, float scale, float* __restrict__ x, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    x[i] = r[i] + scale * h[i] * drop_mul(d, (uint64_t)i, thr, ik);
+}
+__global__ __launch_bounds__(256) void scale_drop_kernel(const float* __restrict__ dx, float scale, float* __restrict__ dh, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dh[i] = scale * dx[i] * drop_mul(d, (uint64_t)i, thr, ik);
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+static dim3 pw_grid(long n) { return dim3((unsigned)min((n + 255) / 256, (long)(256 * 16))); }
+hipError_t launch_silu_drop_fwd(const float* pre, float* act, long n, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(silu_drop_fwd_kernel, pw_grid(n), dim3(256), 0, st, pre, act, n, d);
+  return hipGetLastError();
+}
+hipError_t launch_silu_drop_bwd(const float* dact, const float* pre, float* dpre, long n, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(silu_drop_bwd_kernel, pw_grid(n), dim3(256), 0, st, dact, pre, dpre, n, d);
+  return hipGetLastError();
+}
+hipError_t launch_residual_drop_fwd(const float* r, const float* h, float scale, float* x, long n, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(residual_drop_fwd_kernel, pw_grid(n), dim3(256), 0, st, r, h, scale, x, n, d);
+  return hipGetLastError();
+}
+hipError_t launch_scale_drop(const float* dx, float scale, float* dh, long n, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(scale_drop_kernel, pw_grid(n), dim3(256), 0, st, dx, scale, dh, n, d);
+  return hipGetLastError();
+}
+hipError_t launch_axpy(float* y, const float* x, float a, long n, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, pw_grid(n), dim3(256), 0, st, y, x, a, n);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void glu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, long n, int D) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    g[i] = u[r * 2 * D + c] * sigmoidf_(u[r * 2 * D + D + c]);
+  }
+}
+__global__ __launch_bounds__(256) void glu_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ u, float* __restrict__ du, long n, int D) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long r = i / D;
+    const int c = (int)(i - r * D);
+    const float a = u[r * 2 * D + c], s = sigmoidf_(u[r * 2 * D + D + c]), d = dg[i];
+    du[r * 2 * D + c] = d * s;
+    du[r * 2 * D + D + c] = d * a * s * (1.0f - s);
+  }
+}
+hipError_t launch_glu_fwd(const float* u, float* g, int M, int D, hipStream_t st) {
+  hipLaunchKernelGGL(glu_fwd_kernel, pw_grid((long)M * D), dim3(256), 0, st, u, g, (long)M * D, D);
+  return hipGetLastError();
+}
+hipError_t launch_glu_bwd(const float* dg, const float* u, float* du, int M, int D, hipStream_t st) {
+  hipLaunchKernelGGL(glu_bwd_kernel, pw_grid((long)M * D), dim3(256), 0, st, dg, u, du, (long)M * D, D);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// depthwise conv over time
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kDwMaxK = 31;
+constexpr int kDwRows = 16;  // time steps per block
+// y[b][t][d] = bias[d] + sum_j w[d][FLIP ? K-1-j : j] * x[b][t + j - pad][d]
+template <bool FLIP>
+__global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                 float* __restrict__ y, int T, int D, int K) {
+  const int b = blockIdx.y, t0 = blockIdx.x * kDwRows, pad = (K - 1) / 2;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float wt[kDwMaxK];
+#pragma unroll
+    for (int j = 0; j < kDwMaxK; ++j) wt[j] = j < K ? w[(long)d * K + (FLIP ? K - 1 - j : j)] : 0.0f;
+    const float bv = bias ? bias[d] : 0.0f;
+    for (int t = t0; t < min(T, t0 + kDwRows); ++t) {
+      float s = bv;
+#pragma unroll
+      for (int j = 0; j < kDwMaxK; ++j) {
+        const int tt = t + j - pad;
+        if (j < K && tt >= 0 && tt < T) s += wt[j] * x[((long)b * T + tt) * D + d];
+      }
+      y[((long)b * T + t) * D + d] = s;
+    }
+  }
+}
+hipError_t launch_dw_fwd(const float* x, const float* w, const float* b, float* y, int B, int T, int D, int K, hipStream_t st) {
+  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dw_kernel<false>, dim3((T + kDwRows - 1) / kDwRows, B), dim3(256), 0, st, x, w, b, y, T, D, K);
+  return hipGetLastError();
+}
+hipError_t launch_dw_bwd_data(const float* dy, const float* w, float* dx, int B, int T, int D, int K, hipStream_t st) {
+  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dw_kernel<true>, dim3((T + kDwRows - 1) / kDwRows, B), dim3(256), 0, st, dy, w, (const float*)nullptr, dx, T, D, K);
+  return hipGetLastError();
+}
+constexpr int kDwwRows = 64;
+int dw_bwd_weight_blocks(int B, int T) { return B * ((T + kDwwRows - 1) / kDwwRows); }
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
+                                                            int T, int D, int K) {
+  const int nchunk = (T + kDwwRows - 1) / kDwwRows, b = blockIdx.x / nchunk, t0 = (blockIdx.x % nchunk) * kDwwRows, pad = (K - 1) / 2;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float acc[kDwMaxK + 1];
+#pragma unroll
+    for (int j = 0; j <= kDwMaxK; ++j) acc[j] = 0.0f;
+    for (int t = t0; t < min(T, t0 + kDwwRows); ++t) {
+      const float g = dy[((long)b * T + t) * D + d];
+      acc[kDwMaxK] += g;
+#pragma unroll
+      for (int j = 0; j < kDwMaxK; ++j) {
+        const int tt = t + j - pad;
+        if (j < K && tt >= 0 && tt < T) acc[j] += g * x[((long)b * T + tt) * D + d];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kDwMaxK; ++j)
+      if (j < K) part[((long)blockIdx.x * (K + 1) + j) * D + d] = acc[j];
+    part[((long)blockIdx.x * (K + 1) + K) * D + d] = acc[kDwMaxK];
+  }
+}
+// dw[d][j] = sum_s part[s][j][d], db[d] = sum_s part[s][K][d]
+__global__ __launch_bounds__(256) void dw_weight_finalize_kernel(const float* __restrict__ part, int S, int D, int K, float* __restrict__ dw, float* __restrict__ db) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= (K + 1) * D) return;
+  const int j = i / D, d = i % D;
+  float s = 0.0f;
+  for (int b = 0; b < S; ++b) s += part[((long)b * (K + 1) + j) * D + d];
+  if (j < K) dw[(long)d * K + j] = s;
+  else db[d] = s;
+}
+hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part, float* dw, float* db, int B, int T, int D, int K, hipStream_t st) {
+  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  const int S = dw_bwd_weight_blocks(B, T);
+  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(S), dim3(256), 0, st, dy, x, part, T, D, K);
+  hipLaunchKernelGGL(dw_weight_finalize_kernel, dim3(((K + 1) * D + 255) / 256), dim3(256), 0, st, (const float*)part, S, D, K, dw, db);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// BatchNorm (batch statistics) + SiLU
+// ---------------------------------------------------------------------------------------------------------------------
+// which == 0: stats[0][c] = mean from part[S][c]; which == 1: stats[1][c] = rstd, mv = (mean, biased var) from part[S][2][c]
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int S, int M, int D, int which, float* __restrict__ stats,
+                                                          float* __restrict__ mv) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  if (which == 0) {
+    float s = 0.0f;
+    for (int i = 0; i < S; ++i) s += part[(long)i * D + c];
+    stats[c] = s / M;
+  } else {
+    float s = 0.0f, q = 0.0f;
+    for (int i = 0; i < S; ++i) s += part[((long)i * 2) * D + c], q += part[((long)i * 2 + 1) * D + c];
+    const float dm = s / M, var = fmaxf(q / M - dm * dm, 0.0f);  // dm ~ 0: the shift was the mean
+    stats[D + c] = rsqrtf(var + 1e-5f);
+    if (mv) mv[c] = stats[c] + dm, mv[D + c] = var;
+  }
+}
+hipError_t launch_bn_stats(const float* c, int M, int D, float* part, float* stats, float* mv, hipStream_t st) {
+  const int S = colsum_blocks(M);
+  hipLaunchKernelGGL(colsum_kernel<false>, dim3(S), dim3(256), 0, st, c, M, D, (const float*)nullptr, part);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, S, M, D, 0, stats, mv);
+  hipLaunchKernelGGL(colsum_kernel<true>, dim3(S), dim3(256), 0, st, c, M, D, (const float*)stats, part);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, S, M, D, 1, stats, mv);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ c, const float* __restrict__ stats, const float* __restrict__ g,
+                                                          const float* __restrict__ b, float* __restrict__ s, long n, int D) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % D);
+    const float y = (c[i] - stats[ch]) * stats[D + ch] * g[ch] + b[ch];
+    s[i] = y * sigmoidf_(y);
+  }
+}
+hipError_t launch_bn_silu_fwd(const float* c, const float* stats, const float* g, const float* b, float* s, int M, int D, hipStream_t st) {
+  hipLaunchKernelGGL(bn_silu_fwd_kernel, pw_grid((long)M * D), dim3(256), 0, st, c, stats, g, b, s, (long)M * D, D);
+  return hipGetLastError();
+}
+// part[blk][0][ch] = sum dy, part[blk][1][ch] = sum dy * xhat over the block's rows
+__global__ __launch_bounds__(256) void bn_silu_bwd_sums_kernel(const float* __restrict__ ds, const float* __restrict__ c, const float* __restrict__ stats,
+                                                               const float* __restrict__ g, const float* __restrict__ b, float* __restrict__ part, int M, int D) {
+  const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
+  for (int ch = threadIdx.x; ch < D; ch += 256) {
+    const float mu = stats[ch], rs = stats[D + ch], gg = g[ch], bb = b[ch];
+    float s0 = 0.0f, s1 = 0.0f;
+    for (int r = r_begin; r < r_end; ++r) {
+      const float xh = (c[(long)r * D + ch] - mu) * rs, y = xh * gg + bb, sg = sigmoidf_(y);
+      const float dy = ds[(long)r * D + ch] * sg * (1.0f + y * (1.0f - sg));
+      s0 += dy, s1 += dy * xh;
+    }
+    part[((long)blockIdx.x * 2) * D + ch] = s0, part[((long)blockIdx.x * 2 + 1) * D + ch] = s1;
+  }
+}
+__global__ __launch_bounds__(256) void bn_silu_bwd_apply_kernel(const float* __restrict__ ds, const float* __restrict__ c, const float* __restrict__ stats,
+                                                                const float* __restrict__ g, const float* __restrict__ b, const float* __restrict__ sums,
+                                                                float* __restrict__ dc, long n, int D, float inv_m) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int ch = (int)(i % D);
+    const float rs = stats[D + ch], xh = (c[i] - stats[ch]) * rs, y = xh * g[ch] + b[ch], sg = sigmoidf_(y);
+    const float dy = ds[i] * sg * (1.0f + y * (1.0f - sg));
+    dc[i] = g[ch] * rs * (dy - sums[ch] * inv_m - xh * sums[D + ch] * inv_m);
+  }
+}
+hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stats, const float* g, const float* b, float* part, float* sums,
+                              float* dc, int M, int D, hipStream_t st) {
+  const int S = colsum_blocks(M);
+  hipLaunchKernelGGL(bn_silu_bwd_sums_kernel, dim3(S), dim3(256), 0, st, ds, c, stats, g, b, part, M, D);
+  hipLaunchKernelGGL(reduce_leading_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, (const float*)part, S, (long)2 * D, (long)2 * D, sums);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, pw_grid((long)M * D), dim3(256), 0, st, ds, c, stats, g, b, (const float*)sums, dc, (long)M * D, D, 1.0f / M);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// softmax over keys (one wave per query row)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, const int32_t* __restrict__ key_len, long rows, int H, int T, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int len = key_len[row / ((long)H * T)];
+  float* s = S + row * T;
+  float mx = -INFINITY;
+  for (int k = lane; k < T; k += 64) mx = fmaxf(mx, k < len ? s[k] * scale : -INFINITY);
+  mx = wave_max(mx);
+  float sum = 0.0f;
+  for (int k = lane; k < T; k += 64) sum += k < len ? __expf(s[k] * scale - mx) : 0.0f;
+  sum = wave_sum(sum);
+  const float inv = 1.0f / sum;  // len == 0: 0 * inf = nan in every column, as torch
+  for (int k = lane; k < T; k += 64) s[k] = k < len ? __expf(s[k] * scale - mx) * inv : (len > 0 ? 0.0f : NAN);
+}
+hipError_t launch_softmax_fwd(float* S, const int32_t* key_len, int B, int H, int T, float scale, hipStream_t st) {
+  const long rows = (long)B * H * T;
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, key_len, rows, H, T, scale);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void drop_copy_kernel(const float* __restrict__ P, float* __restrict__ Pd, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Pd[i] = P[i] * drop_mul(d, (uint64_t)i, thr, ik);
+}
+hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(drop_copy_kernel, pw_grid(n), dim3(256), 0, st, P, Pd, n, d);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows, int T, float scale, Drop d) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const float* p = P + row * T;
+  float* g = dP + row * T;
+  float dot = 0.0f;
+  for (int k = lane; k < T; k += 64) dot += g[k] * drop_mul(d, (uint64_t)(row * T + k), thr, ik) * p[k];
+  dot = wave_sum(dot);
+  for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * drop_mul(d, (uint64_t)(row * T + k), thr, ik) - dot);
+}
+hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st) {
+  const long rows = (long)B * H * T;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T, scale, d);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int M, int V) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (long)row * V;
+  float mx = -INFINITY;
+  for (int k = lane; k < V; k += 64) mx = fmaxf(mx, xr[k]);
+  mx = wave_max(mx);
+  float sum = 0.0f;
+  for (int k = lane; k < V; k += 64) sum += expf(xr[k] - mx);
+  const float lse = mx + logf(wave_sum(sum));
+  for (int k = lane; k < V; k += 64) y[(long)row * V + k] = xr[k] - lse;
+}
+hipError_t launch_logsoftmax_fwd(const float* logits, float* logp, int M, int V, hipStream_t st) {
+  hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, logp, M, V);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// stem helpers
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void im2col_mel_kernel(const float* __restrict__ mel, float* __restrict__ a, int C, int T, int T1, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int col = (int)(i % (3 * C));
+    const long row = i / (3 * C);
+    const int t1 = (int)(row % T1), b = (int)(row / T1), c = col / 3, j = col % 3;
+    a[i] = mel[((long)b * C + c) * T + 2 * t1 + j];
+  }
+}
+hipError_t launch_im2col_mel(const float* mel, float* a, int B, int C, int T, int T1, hipStream_t st) {
+  const long n = (long)B * T1 * 3 * C;
+  hipLaunchKernelGGL(im2col_mel_kernel, pw_grid(n), dim3(256), 0, st, mel, a, C, T, T1, n);
+  return hipGetLastError();
+}
+// to_jc: wp[o][j][c] = w[o][c][j]; else: wp[o][c][j] = w[o][j][c]
+__global__ __launch_bounds__(256) void permute_w3_kernel(const float* __restrict__ w, float* __restrict__ wp, int C, long n, int to_jc) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long o = i / (3 * C);
+    const int r = (int)(i % (3 * C));
+    if (to_jc) { const int j = r / C, c = r % C; wp[i] = w[o * 3 * C + c * 3 + j]; }
+    else { const int c = r / 3, j = r % 3; wp[i] = w[o * 3 * C + j * C + c]; }
+  }
+}
+hipError_t launch_permute_w3(const float* w, float* wp, int O, int C, int to_jc, hipStream_t st) {
+  const long n = (long)O * 3 * C;
+  hipLaunchKernelGGL(permute_w3_kernel, pw_grid(n), dim3(256), 0, st, w, wp, C, n, to_jc);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void col2im_stride2_kernel(const float* __restrict__ G, float* __restrict__ dout1, int T1, int T2, int D, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % D);
+    const long row = i / D;
+    const int t1 = (int)(row % T1), b = (int)(row / T1);
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int u = t1 - j;
+      if (u >= 0 && !(u & 1) && (u >> 1) < T2) s += G[(((long)b * T2 + (u >> 1)) * 3 + j) * D + c];
+    }
+    dout1[i] = s;
+  }
+}
+hipError_t launch_col2im_stride2(const float* G, float* dout1, int B, int T1, int T2, int D, hipStream_t st) {
+  const long n = (long)B * T1 * D;
+  hipLaunchKernelGGL(col2im_stride2_kernel, pw_grid(n), dim3(256), 0, st, G, dout1, T1, T2, D, n);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void add_pe_drop_kernel(float* __restrict__ x, const float* __restrict__ pe, int T, int D, long n, Drop d) {
+  const uint32_t thr = drop_thr(d.p);
+  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % D), t = (int)((i / D) % T);
+    x[i] = (x[i] + pe[(long)t * D + c]) * drop_mul(d, (uint64_t)i, thr, ik);
+  }
+}
+hipError_t launch_add_pe_drop(float* x, const float* pe, int B, int T, int D, Drop d, hipStream_t st) {
+  const long n = (long)B * T * D;
+  hipLaunchKernelGGL(add_pe_drop_kernel, pw_grid(n), dim3(256), 0, st, x, pe, T, D, n, d);
+  return hipGetLastError();
+}
+
+}  // namespace eect

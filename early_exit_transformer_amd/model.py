@@ -243,10 +243,25 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         self._hip_init(d_model, n_head, d_feed_forward, depthwise_kernel_size, n_enc_exits, n_enc_layers,
                        features_length, dec_voc_size, max_len)
 
+    train_passes = 3  # training GEMMs: 3 = bf16 hi/lo split, three MFMA products (~fp32 results); 1 = plain bf16 operands
+
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
         if self.training and torch.is_grad_enabled():
+            if type(self) is Early_conformer and any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("linears.")):
+                return self._forward_train(src, lengths)
             return self._forward_heads_trainable(src, lengths)
         return self._run_encoder(src, lengths)[0]
+
+    def _forward_train(self, src: Tensor, lengths: Tensor) -> Tensor:
+        """The training step's forward (train.py:54) on the HIP training kernels; autograd reaches every parameter."""
+        if not src.is_cuda:
+            raise RuntimeError("the MI355X training step runs on a HIP device only (there is no CPU fallback)")
+        if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
+            raise ValueError(f"src must be [B, {self._cfg.n_mels}, T], got {tuple(src.shape)}")
+        named = [(n, p) for n, p in self.named_parameters()]
+        names = tuple(n for n, _ in named)
+        len_dev = lengths.to(device=src.device, dtype=torch.int64).contiguous()
+        return _EncoderTrainFn.apply(self, src.contiguous().float(), len_dev, names, *[p for _, p in named])
 
     def _forward_heads_trainable(self, src: Tensor, lengths: Tensor) -> Tensor:
         """First slice of the training path (train.py:53-70): the exit heads ``linears.*`` are trainable on a FROZEN
@@ -637,6 +652,112 @@ class _ExitHeadsFn(torch.autograd.Function):
         db = [dl[e].sum(0) for e in range(E)]
         dtaps = torch.stack([dl[e] @ ws[e] for e in range(E)]).reshape(taps.shape) if ctx.need_taps else None
         return (None, dtaps, *dW, *db)
+
+
+def _trainer_check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {capi.load().eec_trainer_last_error().decode(errors='replace')}")
+
+
+def _params_struct(model, tensors: Dict[str, Optional[Tensor]]):
+    """EecParams over ``tensors`` (state_dict names -> tensor or None); returns (struct, keep-alive list)."""
+    E, L = model._cfg.n_exits, model._cfg.layers_per_exit
+
+    def ptr(name: str):
+        t = tensors.get(name)
+        return t.data_ptr() if t is not None else None
+
+    layers = _layer_params(ptr, "conformer", E, L)
+    hw = (C.c_void_p * E)(*[ptr(f"{model._head_attr}.{e}.weight") for e in range(E)])
+    hb = (C.c_void_p * E)(*[ptr(f"{model._head_attr}.{e}.bias") for e in range(E)])
+    st = capi.EecParams(ptr("conv_subsample.sequential.0.weight"), ptr("conv_subsample.sequential.0.bias"),
+                        ptr("conv_subsample.sequential.1.weight"), ptr("conv_subsample.sequential.1.bias"),
+                        ptr(f"{model._pe_attr}.pe"), layers, hw, hb)
+    return st, (layers, hw, hb)
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    """``Early_conformer.forward`` in train mode and its backward on the HIP training kernels (csrc/train.hip): what
+    ``enc_out = model(batch_0, valid_lengths)`` / ``loss.backward()`` do in the reference's train.py:53-68.  BatchNorm uses
+    the batch statistics (and updates running_mean / running_var / num_batches_tracked like nn.BatchNorm1d), dropout
+    runs at the reference's sites with probability ``model.dropout``."""
+
+    @staticmethod
+    def forward(ctx, model, src, len_dev, names, *params):
+        lib = capi.load()
+        dev = src.device
+        cfg = model._cfg
+        B, _, T = src.shape
+        Tq = lib.eec_out_frames(T)
+        E, L, D, V = cfg.n_exits, cfg.layers_per_exit, cfg.d_model, cfg.vocab
+        with torch.cuda.device(dev):
+            if getattr(model, "_trainer", None) is None or model._trainer_device != dev:
+                if getattr(model, "_trainer", None) is not None:
+                    lib.eec_trainer_destroy(model._trainer)
+                h = C.c_void_p()
+                _trainer_check(lib.eec_trainer_create(C.byref(cfg), C.byref(h)), "eec_trainer_create")
+                model._trainer, model._trainer_device = h, dev
+            tensors = dict(zip(names, params))
+            for k, v in model.state_dict(keep_vars=True).items():
+                tensors.setdefault(k, v)
+            for k, t in tensors.items():
+                if t.is_floating_point() and (t.device != dev or t.dtype != torch.float32 or not t.is_contiguous()):
+                    raise RuntimeError(f"parameter {k} must be a contiguous fp32 tensor on {dev}")
+            pst, keep = _params_struct(model, tensors)
+            nbytes = lib.eec_trainer_workspace_bytes(model._trainer, B, T)
+            if nbytes == 0:
+                raise ValueError("unsupported geometry for the training step")
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+            out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev)
+            bn = torch.empty((E * L, 2, D), dtype=torch.float32, device=dev)
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_forward(model._trainer, C.byref(pst), src.data_ptr(), len_dev.data_ptr(), B, T,
+                                                 int(model.train_passes), float(model.dropout), seed, out.data_ptr(), bn.data_ptr(),
+                                                 ws_ptr, nbytes, C.c_void_p(stream)), "eec_train_forward")
+            model._train_generation = getattr(model, "_train_generation", 0) + 1
+            ctx.generation = model._train_generation
+            # running statistics, as nn.BatchNorm1d(momentum=0.1) in train mode
+            n = B * Tq
+            li = 0
+            with torch.no_grad():
+                for grp in model.conformer:
+                    for layer in grp.conformer_layers:
+                        bnm = layer.conv_module.sequential[3]
+                        if bnm.track_running_stats and bnm.running_mean is not None:
+                            m = bnm.momentum if bnm.momentum is not None else 0.1
+                            bnm.running_mean.mul_(1 - m).add_(bn[li, 0], alpha=m)
+                            bnm.running_var.mul_(1 - m).add_(bn[li, 1] * (n / max(n - 1, 1)), alpha=m)
+                            bnm.num_batches_tracked += 1
+                        li += 1
+        ctx.model, ctx.names, ctx.ws, ctx.ws_ptr, ctx.nbytes = model, names, ws, ws_ptr, nbytes
+        ctx.keep = (src, len_dev)
+        ctx.save_for_backward(out, *params)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        model, names = ctx.model, ctx.names
+        if ctx.generation != model._train_generation:
+            raise RuntimeError("the trainer records one forward at a time: run backward before the next training forward")
+        out, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
+        dev = out.device
+        lib = capi.load()
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            tensors = dict(zip(names, params))
+            for k, v in model.state_dict(keep_vars=True).items():
+                tensors.setdefault(k, v)
+            pst, keep = _params_struct(model, tensors)
+            grads = {k: torch.empty_like(v) for k, v in zip(names, params)}
+            gst, gkeep = _params_struct(model, grads)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_backward(model._trainer, C.byref(pst), C.byref(gst), out.data_ptr(), g.data_ptr(),
+                                                  ctx.ws_ptr, ctx.nbytes, C.c_void_p(stream)), "eec_train_backward")
+        ctx.ws = None
+        need = ctx.needs_input_grad[4:]
+        return (None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])
 
 
 class full_conformer(_HipEncoderMixin, nn.Module):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 10
+#define EEC_ABI_VERSION 11
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -246,6 +246,35 @@ int eec_frontend_create(int sample_rate, int n_fft, int win_length, int hop_leng
 void eec_frontend_destroy(eec_frontend* fe);
 int eec_frontend_frames(int n_samples, int hop_length);
 int eec_frontend_forward(eec_frontend* fe, const float* wave, const int64_t* lengths_opt, int B, int Lmax, float* mel, void* stream);
+
+/* ---- Training step of the Early_conformer path (train.py:53-70) -------------------------------------------------
+ * `enc_out = model(batch_0, valid_lengths)` in train mode and `loss.backward()` through it.  Parameters are read in place
+ * as fp32 (eec_params: the nn.Parameter storages themselves, no packing); activations stay fp32 in HBM; GEMM operands are
+ * split into bf16 hi / lo planes on the fly (`passes` 3: three MFMA products per GEMM, ~1e-5 relative; 1: plain bf16).
+ * Semantics of the reference's train mode: BatchNorm1d normalises with the statistics of the batch (all B*T' frames,
+ * padded ones included) -- `bn_batch_stats` [E*L][2][D] returns (mean, biased variance) per layer so the caller can update
+ * running_mean / running_var (momentum 0.1, unbiased variance) --, dropout with probability `drop_prob` at the reference's
+ * sites (after the positional encoding, inside and after each feed-forward module, on the attention probabilities, after
+ * out_proj, after the convolution module) from a counter-based generator keyed by `seed` (its streams cannot match
+ * torch's: parity with the reference is at drop_prob 0).
+ * eec_train_forward records the activations the backward needs in `workspace` (eec_trainer_workspace_bytes; the caller
+ * keeps it untouched until eec_train_backward); one recorded forward per trainer at a time.
+ * eec_train_backward: `out` = the log-probs eec_train_forward returned, `grad_out` = dLoss/d out [E,B,T',V]; `grads` is
+ * an eec_params whose pointers are WRITTEN (overwritten, not accumulated) with the gradient of the parameter at the same
+ * position (pe / running_mean / running_var entries are ignored).  Gradient with respect to `mel` is not produced. */
+typedef struct eec_trainer eec_trainer;
+const char* eec_trainer_last_error(void);
+int eec_trainer_create(const eec_config* cfg, eec_trainer** out);
+void eec_trainer_destroy(eec_trainer* tr);
+size_t eec_trainer_workspace_bytes(const eec_trainer* tr, int B, int T);
+int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* mel, const int64_t* lengths, int B, int T, int passes,
+                      float drop_prob, uint64_t seed, float* out, float* bn_batch_stats, void* workspace, size_t workspace_bytes,
+                      void* stream);
+int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* C = alpha * A . B^T (+ bias) on the training GEMM (test hook): A [M][K], B [N][K], C [M][N] fp32 row-major on the device */
+int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
+                   int b_transposed, void* stream);
 
 #ifdef __cplusplus
 }

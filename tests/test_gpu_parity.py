@@ -350,9 +350,8 @@ def test_error_paths():
         gpu(torch.zeros(1, 80, 99), torch.tensor([99]))
     with pytest.raises(RuntimeError, match="unsupported|256 or 512"):
         Early_conformer(**base_kwargs(d_model=128, n_head=4, device="cuda")).eval().cuda()(torch.zeros(1, 80, 99).cuda(), torch.tensor([99]))
-    gpu.train()
-    with pytest.raises(NotImplementedError):
-        gpu(torch.zeros(1, 80, 99).cuda(), torch.tensor([99]))
+    gpu.train()  # train mode with trainable parameters runs the training step (tests/test_gpu_train.py)
+    assert gpu(torch.zeros(1, 80, 99).cuda(), torch.tensor([99])).requires_grad
 
 
 class TestFullSize:
@@ -814,11 +813,10 @@ def test_exit_heads_trainable_on_frozen_encoder():
     gpu.eval()
     with torch.no_grad():
         assert (gpu(mel.cuda(), lens).cpu() - ref(mel, lens)).abs().max().item() < TOL["f16f8"]
-    # a trainable encoder parameter is still refused
+    # a trainable encoder parameter selects the full training step (tests/test_gpu_train.py)
     gpu.train()
     gpu.conformer[0].conformer_layers[0].ffn1.sequential[1].weight.requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        gpu(mel.cuda(), lens)
+    assert gpu(mel.cuda(), lens).requires_grad
 
 
 def test_mel_frontend_against_oracle():
