@@ -126,6 +126,7 @@ def main():
     ap.add_argument("--precision", default="f16f8", choices=["f16f8", "f16x3", "mixed", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-modes", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step secondary lines")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -237,6 +238,72 @@ def main():
         torch.cuda.synchronize()
         d = time.perf_counter() - t1
         forward_only = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4)}
+
+    # ---- training step (secondary lines; BASELINE.json configs[3] on every rank, configs[2] geometry at N = 1) ----
+    # one step = train.py:53-70: forward in train mode (dropout 0.1, batch-statistics BatchNorm), summed per-exit CTC loss,
+    # backward (HIP training kernels), gradient all-reduce over the ranks (bucketed RCCL, N > 1), clip_grad_norm_, AdamW.
+    def train_bench(cfg, passes, n_steps, label):
+        tm = Early_conformer(device=dev, **cfg)
+        tm.load_state_dict(synth.synth_state_dict(tm.state_dict(), seed=2, style="init"))
+        tm = tm.to(dev).train()
+        tm.train_passes = passes
+        params = list(tm.parameters())
+        opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+        torch.manual_seed(rank)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = exit_ctc_losses(tm(mel, lengths), tgt, tgt_len).sum()
+            loss.backward()
+            parallel.allreduce_gradients(params, B)
+            torch.nn.utils.clip_grad_norm_(params, 1.0)
+            opt.step()
+            return loss
+
+        err = ""
+        d = float("nan")
+        try:
+            for _ in range(2):
+                loss = step()
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(n_steps):
+                loss = step()
+            torch.cuda.synchronize()
+            d = (time.perf_counter() - t1) / n_steps
+            if not torch.isfinite(loss).item():
+                err = "non-finite loss"
+        except Exception as e:  # reported, and every rank still reaches the collective below
+            err = f"{type(e).__name__}: {e}"[:300]
+        if dist is not None:
+            t = torch.tensor([d if not err else float("inf")], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d = float(t.item())
+        del tm, opt, params
+        torch.cuda.empty_cache()
+        if rank != 0:
+            return None
+        f_fwd, _ = flops_per_forward(B, T, D=cfg["d_model"], L=cfg["n_enc_layers"])
+        ok = not err and d == d and d != float("inf")
+        return {"workload": label, "value": round(world * B * T / d, 1) if ok else None, "unit": "mel-frames/s",
+                "ms_per_step": round(d * 1e3, 3) if ok else None, "n_gpus": world, "steps": n_steps,
+                "operands": "bf16x3 (hi/lo split, 3 MFMA products, ~fp32 results)" if passes == 3 else "bf16",
+                "algorithmic_flop_per_step": 3 * f_fwd,
+                "frac_of_mfma_peak": round(3 * f_fwd / d / MFMA_PEAK_FLOPS, 4) if ok else None, "error": err or None}
+
+    train = None
+    if not args.no_modes and not args.no_train:
+        n_tr = max(3, args.steps // 10)
+        lab4 = (f"CTC training step, default 12-layer d_model=256, batch {B}/GPU x {world} GPU(s), mel [80 x {T}] "
+                "(BASELINE.json configs[3]; gradients all-reduced in 64 MB buckets when N > 1)")
+        t_x3 = train_bench(CFG, 3, n_tr, lab4)
+        t_bf = train_bench(CFG, 1, n_tr, lab4)
+        t3 = None
+        if world == 1:
+            t3 = train_bench(dict(CFG, d_model=512, n_enc_layers=3), 1, max(2, n_tr // 2),
+                             f"CTC training step, 18-layer d_model=512 (6 exits x 3), batch {B}, mel [80 x {T}] (BASELINE.json configs[2])")
+        if rank == 0:
+            train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3}
 
     # ---- BASELINE.json configs[2] geometry (secondary line): 6 exits x 3 layers, d_model 512, forward + fused exit losses ----
     config3 = None
@@ -415,6 +482,7 @@ def main():
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
             "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3, "frontend": frontend,
+            "train_step": train,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:

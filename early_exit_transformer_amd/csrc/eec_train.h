@@ -9,6 +9,13 @@
 
 namespace eect {
 
+// dropout site: keep(i) = hash(seed, site, i) >= p * 2^32; kept values are scaled by 1 / (1 - p).  p == 0: identity.
+struct Drop {
+  float p;
+  uint64_t seed;
+  uint32_t site;
+};
+
 // C[z](m, n) = alpha * sum_k A[z](m, k) * B[z](n, k)  (+ bias[n])  (+ C[z](m, n) if accumulate)
 // A(m, k) = A[a_m * m + a_k * k], B(n, k) = B[b_n * n + b_k * k]: for each operand ONE of its two strides must be 1
 // (k-contiguous operands are staged with 8-byte LDS stores, row-contiguous ones are transposed on the way in).
@@ -25,6 +32,11 @@ struct GemmArgs {
   float alpha;
   const float* bias;
   int accumulate;
+  // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux)
+  int epi;
+  float* C2;
+  const float* aux;
+  Drop drop;
 };
 inline GemmArgs gemm_args(const float* A, long a_m, long a_k, const float* B, long b_n, long b_k, float* C, long c_m, int M, int N, int K) {
   GemmArgs g{};
@@ -33,13 +45,6 @@ inline GemmArgs gemm_args(const float* A, long a_m, long a_k, const float* B, lo
   return g;
 }
 hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st);
-
-// dropout site: keep(i) = hash(seed, site, i) >= p * 2^32; kept values are scaled by 1 / (1 - p).  p == 0: identity.
-struct Drop {
-  float p;
-  uint64_t seed;
-  uint32_t site;
-};
 
 // LayerNorm over the last dimension (eps 1e-5, affine): y = (x - mean) * rstd * g + b; mean / rstd [M] are kept
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, int D, hipStream_t st);
@@ -68,7 +73,7 @@ hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part /*[
                                 int B, int T, int D, int K, hipStream_t st);
 
 // BatchNorm1d in train mode + SiLU: stats [2][D] = (batch mean, rstd = 1 / sqrt(biased var + 1e-5)); mv [2][D] = (mean, biased var)
-hipError_t launch_bn_stats(const float* c, int M, int D, float* part /*[colsum_blocks(M)][2][D]*/, float* stats, float* mv, hipStream_t st);
+hipError_t launch_bn_stats(const float* c, int M, int D, float* part /*[colsum_blocks(M) + 1][2][D]*/, float* stats, float* mv, hipStream_t st);
 hipError_t launch_bn_silu_fwd(const float* c, const float* stats, const float* g, const float* b, float* s, int M, int D, hipStream_t st);
 // sums [2][D] = (sum dy, sum dy * xhat) with dy = ds * silu'(bn(c)); then dc
 hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stats, const float* g, const float* b, float* part, float* sums,

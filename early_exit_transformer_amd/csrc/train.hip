@@ -39,7 +39,7 @@ struct Bump {  // bump allocator; base == nullptr: sizes only
 };
 
 struct FfnTape {
-  float *x, *ln, *mean, *rstd, *pre;
+  float *x, *ln, *mean, *rstd, *pre, *act;
   uint32_t site_act, site_res;
 };
 struct AttnTape {
@@ -149,14 +149,17 @@ void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const floa
 float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.pre = r.tape.f((size_t)M * F);
+  t.act = r.tape.f((size_t)M * F);
   t.site_act = r.site++, t.site_res = r.site++;
   RUN(launch_ln_fwd(x, ln_w, ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
-  linear_fwd(r, t.ln, w1, b1, t.pre, M, F, D);
+  {  // pre = LN(x) . W1^T + b1 and, in the same epilogue, act = drop(silu(pre))
+    GemmArgs g = gemm_args(t.ln, D, 1, w1, D, 1, t.pre, F, M, F, D);
+    g.bias = b1, g.epi = 1, g.C2 = t.act, g.drop = drop_of(r, t.site_act);
+    RUN(launch_gemm(g, r.tr->np, r.st));
+  }
   r.scr.reset();
-  float* act = r.scr.f((size_t)M * F);
   float* h = r.scr.f((size_t)M * D);
-  RUN(launch_silu_drop_fwd(t.pre, act, (long)M * F, drop_of(r, t.site_act), r.st));
-  linear_fwd(r, act, w2, b2, h, M, D, F);
+  linear_fwd(r, t.act, w2, b2, h, M, D, F);
   float* y = r.tape.f((size_t)M * D);
   RUN(launch_residual_drop_fwd(x, h, 0.5f, y, (long)M * D, drop_of(r, t.site_res), r.st));
   return y;
@@ -224,7 +227,7 @@ float* conv_fwd(Run& r, ConvTape& t, float* x, const eec_layer_params& L, float*
   RUN(launch_glu_fwd(t.u, t.g, M, D, r.st));
   RUN(launch_dw_fwd(t.g, L.conv_dw_w, L.conv_dw_b, t.c, tr->B, tr->Tq, D, K, r.st));
   r.scr.reset();
-  float* part = r.scr.f((size_t)colsum_blocks(M) * 2 * D);
+  float* part = r.scr.f((size_t)(colsum_blocks(M) + 1) * 2 * D);
   RUN(launch_bn_stats(t.c, M, D, part, t.stats, bn_mv, r.st));
   RUN(launch_bn_silu_fwd(t.c, t.stats, L.conv_bn_w, L.conv_bn_b, t.s, M, D, r.st));
   float* v = r.scr.f((size_t)M * D);
@@ -280,15 +283,16 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
   r.scr.reset();
   float* dh = r.scr.f((size_t)M * D);
-  float* act = r.scr.f((size_t)M * F);
-  float* dact = r.scr.f((size_t)M * F);
+  float* dpre = r.scr.f((size_t)M * F);
   RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
-  RUN(launch_silu_drop_fwd(t.pre, act, (long)M * F, drop_of(r, t.site_act), r.st));
-  linear_bwd_weight(r, dh, act, g_w2, g_b2, M, D, F);
-  linear_bwd_data(r, dh, w2, dact, M, D, F);
-  RUN(launch_silu_drop_bwd(dact, t.pre, dact, (long)M * F, drop_of(r, t.site_act), r.st));
-  linear_bwd_weight(r, dact, t.ln, g_w1, g_b1, M, F, D);
-  linear_bwd_data(r, dact, w1, dh, M, F, D);  // dh now holds d LN-output
+  linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
+  {  // dpre = (dh . W2) * dropmask * silu'(pre), the activation's backward in the GEMM epilogue
+    GemmArgs g = gemm_args(dh, D, 1, w2, 1, F, dpre, F, M, F, D);
+    g.epi = 2, g.aux = t.pre, g.drop = drop_of(r, t.site_act);
+    RUN(launch_gemm(g, r.tr->np, r.st));
+  }
+  linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
+  linear_bwd_data(r, dpre, w1, dh, M, F, D);  // dh now holds d LN-output
   ln_bwd(r, dh, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
 }
 

@@ -29,56 +29,119 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---------------------------------------------------------------------------------------------------------------------
 // dropout
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool drop_keep(const Drop& d, uint64_t i, uint32_t thr) {
-  uint64_t x = i + d.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)d.site << 44);
+// counter-based: 32-bit mix (lowbias32) of the element index keyed by (seed, site)
+__device__ __forceinline__ uint32_t drop_key(const Drop& d) {
+  uint64_t x = d.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)d.site << 32 | d.site);
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (uint32_t)(x >> 32) >= thr;
+  return (uint32_t)(x >> 32) ^ (uint32_t)x;
+}
+__device__ __forceinline__ bool drop_keep(uint32_t key, uint64_t i, uint32_t thr) {
+  uint32_t h = (uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + key;
+  h ^= h >> 16, h *= 0x7FEB352Du, h ^= h >> 15, h *= 0x846CA68Bu, h ^= h >> 16;
+  return h >= thr;
 }
 __device__ __forceinline__ uint32_t drop_thr(float p) {
   const double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
-// multiplier of element i under dropout d (1 when p == 0)
-__device__ __forceinline__ float drop_mul(const Drop& d, uint64_t i, uint32_t thr, float inv_keep) {
-  if (d.p <= 0.0f) return 1.0f;
-  return drop_keep(d, i, thr) ? inv_keep : 0.0f;
-}
+// per-thread dropout state of one site; mul(i) = multiplier of element i (1 when p == 0)
+struct DropState {
+  uint32_t key, thr;
+  float inv_keep;
+  bool on;
+  __device__ __forceinline__ explicit DropState(const Drop& d)
+      : key(drop_key(d)), thr(drop_thr(d.p)), inv_keep(d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f), on(d.p > 0.0f) {}
+  __device__ __forceinline__ float mul(uint64_t i) const { return !on ? 1.0f : (drop_keep(key, i, thr) ? inv_keep : 0.0f); }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load4(float (&v)[4], const float* p, long step, int nv) {
-  if (nv == 4 && step == 1 && (((uintptr_t)p) & 15) == 0) {
-    const f32x4 q = *(const f32x4*)p;
-    v[0] = q[0], v[1] = q[1], v[2] = q[2], v[3] = q[3];
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = j < nv ? p[j * step] : 0.0f;
-  }
-}
-
-// R x 32 tile of an operand X(r, k) = X[s_r * r + s_k * k] into registers: 4 consecutive elements along the unit-stride axis
+// LDS image of one operand tile (R rows x 32 k), two layouts:
+//   KC (the operand is k-contiguous in memory): [R][kLdk] bf16, fragments read with ds_read_b128;
+//   transposed (row-contiguous in memory): [32 k][ldt(R)] bf16 -- stored as it arrives, 4 consecutive rows per thread with
+//   one 8-byte store -- and read back through ds_read_b64_tr_b16, the hardware transpose: a 16-lane group reads a
+//   4 (k) x 16 (rows) block and every lane receives the 4 k-values of its row.  ldt = R + 32 (R for R = 32) puts the four
+//   k-rows of a block on disjoint bank quarters.
 template <int R>
-__device__ __forceinline__ void load_tile(float (&reg)[R / 32][4], const float* __restrict__ X, long s_r, long s_k, int r0, int k0,
-                                          int Rmax, int K, bool kc, int tid) {
+struct TileGeo {
+  static constexpr int kLdt = R == 32 ? 32 : R + 32;
+  static constexpr int kElems = R * kLdk > 32 * kLdt ? R * kLdk : 32 * kLdt;
+};
+
+// Loader of the R x 32 tiles of one operand X(r, k) = X[s_r * r + s_k * k] (one of the strides is 1): each thread owns
+// R / 32 groups of 4 consecutive elements along the unit-stride axis.  Pointers and row validity are set up once; a full
+// interior tile is R / 32 unchecked 16-byte loads per thread, edges (last k-tile, ragged rows, unaligned bases) go element-wise.
+template <int R, bool KC>
+struct TileLoader {
+  const float* p[R / 32];
+  const float* x0;          // the operand's base (uniform)
+  uint32_t off[R / 32];     // this thread's element offsets from x0 + k0 * kstep, rows clamped into the matrix (fast path)
+  int nv[R / 32];  // KC: 4 if the row exists else 0; transposed: how many of the thread's 4 rows exist
+  long kstep;      // elements between consecutive k
+  bool vec;        // every 4-element group is 16-byte aligned
+  bool clean;      // vec, and no 4-row group of a transposed operand straddles the last row
+  __device__ __forceinline__ void init(const float* __restrict__ X, long s_r, long s_k, int r0, int Rmax, int tid) {
+    kstep = KC ? 1 : s_k;
+    x0 = X;
+    vec = (((uintptr_t)X) & 15) == 0 && ((KC ? s_r : s_k) & 3) == 0;
+    clean = vec && (KC || (Rmax & 3) == 0);
 #pragma unroll
-  for (int it = 0; it < R / 32; ++it) {
-    const int idx = it * 256 + tid;
-    if (kc) {
-      const int r = r0 + (idx >> 3), k = k0 + (idx & 7) * 4;
-      const int nv = r < Rmax ? min(max(K - k, 0), 4) : 0;
-      load4(reg[it], X + (long)r * s_r + k, 1, nv);
-    } else {
-      const int r = r0 + (idx % (R / 4)) * 4, k = k0 + idx / (R / 4);
-      const int nv = k < K ? min(max(Rmax - r, 0), 4) : 0;
-      load4(reg[it], X + (long)k * s_k + r, 1, nv);
+    for (int it = 0; it < R / 32; ++it) {
+      const int idx = it * 256 + tid;
+      if (KC) {
+        const int r = r0 + (idx >> 3);
+        nv[it] = r < Rmax ? 4 : 0;
+        p[it] = X + (long)min(r, Rmax - 1) * s_r + (idx & 7) * 4;  // clamped: always a readable row
+        off[it] = (uint32_t)(p[it] - X);
+      } else {
+        const int r = r0 + (idx % (R / 4)) * 4;
+        nv[it] = min(max(Rmax - r, 0), 4);
+        p[it] = X + (long)(idx / (R / 4)) * s_k + r;  // the element-wise path wants the true rows
+        off[it] = (uint32_t)((long)(idx / (R / 4)) * s_k + min(r, max(Rmax - 4, 0)));
+      }
     }
   }
-}
-template <int R, int NP>
-__device__ __forceinline__ void store_tile(bf16* __restrict__ hi, bf16* __restrict__ lo, const float (&reg)[R / 32][4], bool kc, int tid) {
+  // interior tile of a clean operand: R / 32 unchecked 16-byte loads off one uniform base.  Rows past the end were clamped
+  // to existing ones: they only feed accumulator rows / columns that the epilogue never stores.
+  __device__ __forceinline__ void load_fast(float (&reg)[R / 32][4], int k0) const {
+    const float* __restrict__ b = x0 + (long)k0 * kstep;
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+      const f32x4 v = *(const f32x4*)(b + off[it]);
+      reg[it][0] = v[0], reg[it][1] = v[1], reg[it][2] = v[2], reg[it][3] = v[3];
+    }
+  }
+  __device__ __forceinline__ void load(float (&reg)[R / 32][4], int k0, int K, int tid) const {
+    const bool full = k0 + kBK <= K;  // uniform
+#pragma unroll
+    for (int it = 0; it < R / 32; ++it) {
+      const float* q = p[it] + (long)k0 * kstep;
+      if (KC) {
+        if (vec && full) {
+          const f32x4 v = *(const f32x4*)q;
+          reg[it][0] = v[0], reg[it][1] = v[1], reg[it][2] = v[2], reg[it][3] = v[3];
+        } else {
+          const int k = k0 + ((it * 256 + tid) & 7) * 4;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) reg[it][j] = (nv[it] != 0 && k + j < K) ? q[j] : 0.0f;
+        }
+      } else {
+        const bool kok = k0 + (it * 256 + tid) / (R / 4) < K;
+        if (vec && full && nv[it] == 4) {
+          const f32x4 v = *(const f32x4*)q;
+          reg[it][0] = v[0], reg[it][1] = v[1], reg[it][2] = v[2], reg[it][3] = v[3];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) reg[it][j] = (kok && j < nv[it]) ? q[j] : 0.0f;
+        }
+      }
+    }
+  }
+};
+template <int R, int NP, bool KC>
+__device__ __forceinline__ void store_tile(bf16* __restrict__ hi, bf16* __restrict__ lo, const float (&reg)[R / 32][4], int tid) {
 #pragma unroll
   for (int it = 0; it < R / 32; ++it) {
     const int idx = it * 256 + tid;
@@ -86,38 +149,47 @@ __device__ __forceinline__ void store_tile(bf16* __restrict__ hi, bf16* __restri
     const bf16x4 h = __builtin_convertvector(x, bf16x4);
     bf16x4 l;
     if (NP == 3) l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
-    if (kc) {
-      const int r = idx >> 3, k = (idx & 7) * 4;
-      *(bf16x4*)(hi + r * kLdk + k) = h;
-      if (NP == 3) *(bf16x4*)(lo + r * kLdk + k) = l;
-    } else {
-      const int r = (idx % (R / 4)) * 4, k = idx / (R / 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hi[(r + j) * kLdk + k] = h[j];
-        if (NP == 3) lo[(r + j) * kLdk + k] = l[j];
-      }
-    }
+    const int off = KC ? (idx >> 3) * kLdk + (idx & 7) * 4 : (idx / (R / 4)) * TileGeo<R>::kLdt + (idx % (R / 4)) * 4;
+    *(bf16x4*)(hi + off) = h;
+    if (NP == 3) *(bf16x4*)(lo + off) = l;
   }
 }
+// MFMA operand fragment (8 consecutive k of row rbase + lane % 32, k half lane / 32) of k-step ks from a tile image
+template <int R, bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const bf16* __restrict__ t, int rbase, int ks, int lane) {
+  if (KC) return *(const bf16x8*)(t + (rbase + (lane & 31)) * kLdk + ks * 16 + (lane >> 5) * 8);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const int i = lane & 15, gi = lane >> 4;
+  const bf16* a = t + (ks * 16 + 8 * (gi >> 1) + (i >> 2)) * TileGeo<R>::kLdt + rbase + 16 * (gi & 1) + 4 * (i & 3);
+  const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * TileGeo<R>::kLdt));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 
-template <int TM, int TN, int WGM, int WGN, int NP>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+template <bool V>
+struct FastTag {
+  static constexpr bool value = V;
+};
+
+// epilogue variants: C = v;  EPI_SILU: also C2 = drop(silu(v));  EPI_DSILU: C = v * dropmask * silu'(aux)
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2 };
+
+template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  __shared__ __attribute__((aligned(16))) bf16 a_hi[BM * kLdk];
-  __shared__ __attribute__((aligned(16))) bf16 a_lo[NP == 3 ? BM * kLdk : 8];
-  __shared__ __attribute__((aligned(16))) bf16 b_hi[BN * kLdk];
-  __shared__ __attribute__((aligned(16))) bf16 b_lo[NP == 3 ? BN * kLdk : 8];
+  __shared__ __attribute__((aligned(16))) bf16 a_hi[TileGeo<BM>::kElems];
+  __shared__ __attribute__((aligned(16))) bf16 a_lo[NP == 3 ? TileGeo<BM>::kElems : 8];
+  __shared__ __attribute__((aligned(16))) bf16 b_hi[TileGeo<BN>::kElems];
+  __shared__ __attribute__((aligned(16))) bf16 b_lo[NP == 3 ? TileGeo<BN>::kElems : 8];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
   const int z0 = blockIdx.z / g.zdiv, z1 = blockIdx.z % g.zdiv;
   const float* __restrict__ A = g.A + z0 * g.a_z0 + z1 * g.a_z1;
   const float* __restrict__ B = g.B + z0 * g.b_z0 + z1 * g.b_z1;
   float* __restrict__ C = g.C + z0 * g.c_z0 + z1 * g.c_z1;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const bool a_kc = g.a_k == 1, b_kc = g.b_k == 1;
-  const long a_r = a_kc ? g.a_m : 1, a_s = a_kc ? 1 : g.a_k;  // (row stride, k stride) as load_tile wants them
-  const long b_r = b_kc ? g.b_n : 1, b_s = b_kc ? 1 : g.b_k;
+  const long a_r = AKC ? g.a_m : 1, a_s = AKC ? 1 : g.a_k;  // (row stride, k stride) as load_tile wants them
+  const long b_r = BKC ? g.b_n : 1, b_s = BKC ? 1 : g.b_k;
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -125,34 +197,48 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  float ra[BM / 32][4], rb[BN / 32][4];
+  // two register stages: the global loads of tile kt + 2 are issued as soon as stage (kt & 1) has been written to LDS, so
+  // they have the MFMA phases of two k-tiles to land (one phase does not cover the L2 / HBM latency)
+  float ra0[BM / 32][4], rb0[BN / 32][4], ra1[BM / 32][4], rb1[BN / 32][4];
   const int K = g.ktot > 0 ? min(g.K, g.ktot - z0 * g.K) : g.K;
   const int nk = (K + kBK - 1) / kBK;
-  load_tile<BM>(ra, A, a_r, a_s, m0, 0, g.M, K, a_kc, tid);
-  load_tile<BN>(rb, B, b_r, b_s, n0, 0, g.N, K, b_kc, tid);
-  for (int kt = 0; kt < nk; ++kt) {
-    store_tile<BM, NP>(a_hi, a_lo, ra, a_kc, tid);
-    store_tile<BN, NP>(b_hi, b_lo, rb, b_kc, tid);
-    __syncthreads();
-    if (kt + 1 < nk) {
-      load_tile<BM>(ra, A, a_r, a_s, m0, (kt + 1) * kBK, g.M, K, a_kc, tid);
-      load_tile<BN>(rb, B, b_r, b_s, n0, (kt + 1) * kBK, g.N, K, b_kc, tid);
+  TileLoader<BM, AKC> la;
+  TileLoader<BN, BKC> lb;
+  la.init(A, a_r, a_s, m0, g.M, tid);
+  lb.init(B, b_r, b_s, n0, g.N, tid);
+  // k-tiles are walked in a rotated order that differs between neighbouring workgroups: with power-of-two leading
+  // dimensions the rows of a k-contiguous tile all fall on the same few L2 / HBM channels for a given k offset, and
+  // workgroups in lockstep would all hit those at once (measured: 101 -> TFLOP/s class of the transposed layouts)
+  const int rot = (int)((blockIdx.x * 3 + blockIdx.y + blockIdx.z) % (unsigned)nk);
+  auto k_of = [&](int kt) { const int t = kt + rot; return (t >= nk ? t - nk : t) * kBK; };
+  // fast: every tile of both operands is a full, aligned interior tile -- the loop then carries no bounds logic at all
+  const bool fast = la.clean && lb.clean && (K % kBK) == 0;
+  auto load_ab = [&](float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], int k0, auto fast_tag) {
+    if (decltype(fast_tag)::value) {
+      la.load_fast(ra, k0);
+      lb.load_fast(rb, k0);
+    } else {
+      la.load(ra, k0, K, tid);
+      lb.load(rb, k0, K, tid);
     }
+  };
+  auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) {
+    store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
+    store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
+    __syncthreads();
+    if (kt + 2 < nk) load_ab(ra, rb, k_of(kt + 2), fast_tag);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-      const int ko = ks * 16 + (lane >> 5) * 8;
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) {
-        const int r = (wm * TM + mt) * 32 + (lane & 31);
-        ah[mt] = *(const bf16x8*)(a_hi + r * kLdk + ko);
-        if (NP == 3) al[mt] = *(const bf16x8*)(a_lo + r * kLdk + ko);
+        ah[mt] = read_frag<BM, AKC>(a_hi, (wm * TM + mt) * 32, ks, lane);
+        if (NP == 3) al[mt] = read_frag<BM, AKC>(a_lo, (wm * TM + mt) * 32, ks, lane);
       }
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
-        const int r = (wn * TN + nt) * 32 + (lane & 31);
-        bh[nt] = *(const bf16x8*)(b_hi + r * kLdk + ko);
-        if (NP == 3) bl[nt] = *(const bf16x8*)(b_lo + r * kLdk + ko);
+        bh[nt] = read_frag<BN, BKC>(b_hi, (wn * TN + nt) * 32, ks, lane);
+        if (NP == 3) bl[nt] = read_frag<BN, BKC>(b_lo, (wn * TN + nt) * 32, ks, lane);
       }
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
@@ -166,7 +252,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
     }
     __syncthreads();
-  }
+  };
+  auto k_loop = [&](auto fast_tag) {
+    load_ab(ra0, rb0, k_of(0), fast_tag);
+    if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
+    for (int kt = 0; kt < nk; kt += 2) {
+      k_tile(kt, ra0, rb0, fast_tag);
+      if (kt + 1 < nk) k_tile(kt + 1, ra1, rb1, fast_tag);
+    }
+  };
+  if (fast) k_loop(FastTag<true>{});
+  else k_loop(FastTag<false>{});
+  // epilogue: the values an element needs from memory (old C, aux) are gathered per 32x32 block before any store
+  const DropState ds(g.drop);
+  const float* __restrict__ aux = g.aux;
+  float* __restrict__ C2 = g.C2;
 #pragma unroll
   for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
@@ -174,14 +274,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const int n = n0 + (wn * TN + nt) * 32 + (lane & 31);
       if (n >= g.N) continue;
       const float bias = g.bias ? g.bias[n] : 0.0f;
+      const int mb = m0 + (wm * TM + mt) * 32;
+      float old[16], ax[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int m = m0 + (wm * TM + mt) * 32 + acc_row(i, lane);
+        const int m = mb + acc_row(i, lane);
+        const long ci = (long)m * g.c_m + n;
+        old[i] = (g.accumulate && m < g.M) ? C[ci] : 0.0f;
+        ax[i] = (g.epi == EPI_DSILU && m < g.M) ? aux[ci] : 0.0f;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int m = mb + acc_row(i, lane);
         if (m >= g.M) continue;
-        float v = g.alpha * acc[mt][nt][i] + bias;
-        float* p = C + (long)m * g.c_m + n;
-        if (g.accumulate) v += *p;
-        *p = v;
+        const long ci = (long)m * g.c_m + n;
+        float v = g.alpha * acc[mt][nt][i] + bias + old[i];
+        if (g.epi == EPI_DSILU) {
+          const float sg = 1.0f / (1.0f + __expf(-ax[i]));
+          v *= ds.mul((uint64_t)ci) * sg * (1.0f + ax[i] * (1.0f - sg));
+        }
+        C[ci] = v;
+        if (g.epi == EPI_SILU) C2[ci] = v / (1.0f + __expf(-v)) * ds.mul((uint64_t)ci);
       }
     }
 }
@@ -190,16 +303,33 @@ template <int TM, int TN, int WGM, int WGN>
 static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nz);
-  if (np == 1) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, 1>), grid, dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, 3>), grid, dim3(256), 0, st, g);
+  const bool akc = g.a_k == 1, bkc = g.b_k == 1;
+#define EECT_GEMM(NP, AK, BK) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK>), grid, dim3(256), 0, st, g)
+  if (np == 1) {
+    if (akc && bkc) EECT_GEMM(1, true, true);
+    else if (akc) EECT_GEMM(1, true, false);
+    else if (bkc) EECT_GEMM(1, false, true);
+    else EECT_GEMM(1, false, false);
+  } else {
+    if (akc && bkc) EECT_GEMM(3, true, true);
+    else if (akc) EECT_GEMM(3, true, false);
+    else if (bkc) EECT_GEMM(3, false, true);
+    else EECT_GEMM(3, false, false);
+  }
+#undef EECT_GEMM
   return hipGetLastError();
 }
 hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nz <= 0) return hipSuccess;
   if ((g.a_m != 1 && g.a_k != 1) || (g.b_n != 1 && g.b_k != 1)) return hipErrorInvalidValue;
-  if (g.N <= 32) return launch_gemm_t<1, 1, 4, 1>(g, np, st);  // 128 x 32 tiles
-  if (g.N <= 64) return launch_gemm_t<2, 1, 2, 2>(g, np, st);  // 128 x 64
-  return launch_gemm_t<2, 2, 2, 2>(g, np, st);                 // 128 x 128
+  if (g.epi != EPI_NONE && (g.nz != 1 || g.accumulate)) return hipErrorInvalidValue;  // the epilogues index C as one [M][N] matrix
+  auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nz; };
+  // the largest tile that still gives every CU two workgroups
+  if (g.N <= 32) return launch_gemm_t<1, 1, 4, 1>(g, np, st);  // 128 x 32
+  if (g.N > 64 && wgs(128, 128) >= 512) return launch_gemm_t<2, 2, 2, 2>(g, np, st);
+  if (wgs(128, 64) >= 512 || g.N <= 64) return launch_gemm_t<2, 1, 2, 2>(g, np, st);
+  if (wgs(128, 128) >= 384) return launch_gemm_t<2, 2, 2, 2>(g, np, st);
+  return launch_gemm_t<1, 1, 2, 2>(g, np, st);  // 64 x 64
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -241,7 +371,7 @@ hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* 
   return hipGetLastError();
 }
 
-int ln_bwd_blocks(int M) { return max(1, min(256, (M + 15) / 16)); }
+int ln_bwd_blocks(int M) { return max(1, min(1024, (M + 7) / 8)); }
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ part, int M, int D) {
@@ -293,15 +423,34 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const 
   return hipGetLastError();
 }
 
+// out[j] = sum_s part[s * stride + j]: SL partial sums per column in flight (256 / SL columns per block), summed through LDS
+template <int SL>
 __global__ __launch_bounds__(256) void reduce_leading_kernel(const float* __restrict__ part, int S, long stride, long n, float* __restrict__ out) {
-  const long j = (long)blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  float s = 0.0f;
-  for (int i = 0; i < S; ++i) s += part[(long)i * stride + j];
-  out[j] = s;
+  constexpr int COLS = 256 / SL;
+  __shared__ float red[SL][COLS];
+  const int c = threadIdx.x % COLS, sl = threadIdx.x / COLS;
+  const long j = (long)blockIdx.x * COLS + c;
+  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+  if (j < n) {
+    int i = sl;
+    for (; i + 3 * SL < S; i += 4 * SL) {
+      s0 += part[(long)i * stride + j], s1 += part[(long)(i + SL) * stride + j];
+      s2 += part[(long)(i + 2 * SL) * stride + j], s3 += part[(long)(i + 3 * SL) * stride + j];
+    }
+    for (; i < S; i += SL) s0 += part[(long)i * stride + j];
+  }
+  red[sl][c] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sl == 0 && j < n) {
+    float t = 0.0f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) t += red[k][c];
+    out[j] = t;
+  }
 }
 hipError_t launch_reduce_leading(const float* part, int S, long stride, long n, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(reduce_leading_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, S, stride, n, out);
+  if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, S, stride, n, out);
+  else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, stride, n, out);
   return hipGetLastError();
 }
 
@@ -312,14 +461,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
   const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
   for (int c = threadIdx.x; c < N; c += 256) {
     const float sh = shift ? shift[c] : 0.0f;
-    float s = 0.0f, q = 0.0f;
-    for (int r = r_begin; r < r_end; ++r) {
-      const float v = X[(long)r * N + c] - sh;
-      s += v;
-      if (SQ) q += v * v;
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f}, q[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int r = r_begin;
+    for (; r + 3 < r_end; r += 4) {  // four independent loads in flight per thread
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float v = X[(long)(r + u) * N + c] - sh;
+        s[u] += v;
+        if (SQ) q[u] += v * v;
+      }
     }
-    if (SQ) part[((long)blockIdx.x * 2) * N + c] = s, part[((long)blockIdx.x * 2 + 1) * N + c] = q;
-    else part[(long)blockIdx.x * N + c] = s;
+    for (; r < r_end; ++r) {
+      const float v = X[(long)r * N + c] - sh;
+      s[0] += v;
+      if (SQ) q[0] += v * v;
+    }
+    const float st = (s[0] + s[1]) + (s[2] + s[3]), qt = (q[0] + q[1]) + (q[2] + q[3]);
+    if (SQ) part[((long)blockIdx.x * 2) * N + c] = st, part[((long)blockIdx.x * 2 + 1) * N + c] = qt;
+    else part[(long)blockIdx.x * N + c] = st;
   }
 }
 hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipStream_t st) {
@@ -333,31 +492,27 @@ hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipS
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __global__ __launch_bounds__(256) void silu_drop_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float x = pre[i];
-    act[i] = x * sigmoidf_(x) * drop_mul(d, (uint64_t)i, thr, ik);
+    act[i] = x * sigmoidf_(x) * ds.mul((uint64_t)i);
   }
 }
 __global__ __launch_bounds__(256) void silu_drop_bwd_kernel(const float* __restrict__ dact, const float* __restrict__ pre, float* __restrict__ dpre, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float x = pre[i], s = sigmoidf_(x);
-    dpre[i] = dact[i] * drop_mul(d, (uint64_t)i, thr, ik) * s * (1.0f + x * (1.0f - s));
+    dpre[i] = dact[i] * ds.mul((uint64_t)i) * s * (1.0f + x * (1.0f - s));
   }
 }
 __global__ __launch_bounds__(256) void residual_drop_fwd_kernel(const float* __restrict__ r, const float* __restrict__ h, float scale, float* __restrict__ x, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    x[i] = r[i] + scale * h[i] * drop_mul(d, (uint64_t)i, thr, ik);
+    x[i] = r[i] + scale * h[i] * ds.mul((uint64_t)i);
 }
 __global__ __launch_bounds__(256) void scale_drop_kernel(const float* __restrict__ dx, float scale, float* __restrict__ dh, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dh[i] = scale * dx[i] * drop_mul(d, (uint64_t)i, thr, ik);
+  const DropState ds(d);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dh[i] = scale * dx[i] * ds.mul((uint64_t)i);
 }
 __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, float a, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
@@ -414,7 +569,9 @@ hipError_t launch_glu_bwd(const float* dg, const float* u, float* du, int M, int
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDwMaxK = 31;
 constexpr int kDwRows = 16;  // time steps per block
-// y[b][t][d] = bias[d] + sum_j w[d][FLIP ? K-1-j : j] * x[b][t + j - pad][d]
+constexpr int kDwStep = 4;   // outputs per thread and window load
+// y[b][t][d] = bias[d] + sum_j w[d][FLIP ? K-1-j : j] * x[b][t + j - pad][d]; a thread owns channel d and produces kDwStep
+// consecutive outputs from one K + kDwStep - 1 long window of x (loads are coalesced over d)
 template <bool FLIP>
 __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ y, int T, int D, int K) {
@@ -424,14 +581,20 @@ __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ x, co
 #pragma unroll
     for (int j = 0; j < kDwMaxK; ++j) wt[j] = j < K ? w[(long)d * K + (FLIP ? K - 1 - j : j)] : 0.0f;
     const float bv = bias ? bias[d] : 0.0f;
-    for (int t = t0; t < min(T, t0 + kDwRows); ++t) {
-      float s = bv;
+    for (int t = t0; t < min(T, t0 + kDwRows); t += kDwStep) {
+      float win[kDwMaxK + kDwStep - 1];
 #pragma unroll
-      for (int j = 0; j < kDwMaxK; ++j) {
+      for (int j = 0; j < kDwMaxK + kDwStep - 1; ++j) {
         const int tt = t + j - pad;
-        if (j < K && tt >= 0 && tt < T) s += wt[j] * x[((long)b * T + tt) * D + d];
+        win[j] = (j < K + kDwStep - 1 && tt >= 0 && tt < T) ? x[((long)b * T + tt) * D + d] : 0.0f;
       }
-      y[((long)b * T + t) * D + d] = s;
+#pragma unroll
+      for (int o = 0; o < kDwStep; ++o) {
+        float s = bv;
+#pragma unroll
+        for (int j = 0; j < kDwMaxK; ++j) s += wt[j] * win[j + o];
+        if (t + o < T) y[((long)b * T + t + o) * D + d] = s;
+      }
     }
   }
 }
@@ -454,14 +617,22 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
     float acc[kDwMaxK + 1];
 #pragma unroll
     for (int j = 0; j <= kDwMaxK; ++j) acc[j] = 0.0f;
-    for (int t = t0; t < min(T, t0 + kDwwRows); ++t) {
-      const float g = dy[((long)b * T + t) * D + d];
-      acc[kDwMaxK] += g;
+    for (int t = t0; t < min(T, t0 + kDwwRows); t += kDwStep) {
+      float win[kDwMaxK + kDwStep - 1], g[kDwStep];
 #pragma unroll
-      for (int j = 0; j < kDwMaxK; ++j) {
+      for (int j = 0; j < kDwMaxK + kDwStep - 1; ++j) {
         const int tt = t + j - pad;
-        if (j < K && tt >= 0 && tt < T) acc[j] += g * x[((long)b * T + tt) * D + d];
+        win[j] = (j < K + kDwStep - 1 && tt >= 0 && tt < T) ? x[((long)b * T + tt) * D + d] : 0.0f;
       }
+#pragma unroll
+      for (int o = 0; o < kDwStep; ++o) {
+        g[o] = t + o < min(T, t0 + kDwwRows) ? dy[((long)b * T + t + o) * D + d] : 0.0f;
+        acc[kDwMaxK] += g[o];
+      }
+#pragma unroll
+      for (int j = 0; j < kDwMaxK; ++j)
+#pragma unroll
+        for (int o = 0; o < kDwStep; ++o) acc[j] += g[o] * win[j + o];
     }
 #pragma unroll
     for (int j = 0; j < kDwMaxK; ++j)
@@ -490,29 +661,29 @@ hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part, fl
 // ---------------------------------------------------------------------------------------------------------------------
 // BatchNorm (batch statistics) + SiLU
 // ---------------------------------------------------------------------------------------------------------------------
-// which == 0: stats[0][c] = mean from part[S][c]; which == 1: stats[1][c] = rstd, mv = (mean, biased var) from part[S][2][c]
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int S, int M, int D, int which, float* __restrict__ stats,
+// which == 0: stats[0][c] = mean from sums[c]; which == 1: stats[1][c] = rstd, mv = (mean, biased var) from sums[2][c]
+// (sums of (x - mean) and (x - mean)^2: the first is ~0 and only corrects the mean's rounding)
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, int M, int D, int which, float* __restrict__ stats,
                                                           float* __restrict__ mv) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
   if (which == 0) {
-    float s = 0.0f;
-    for (int i = 0; i < S; ++i) s += part[(long)i * D + c];
-    stats[c] = s / M;
+    stats[c] = sums[c] / M;
   } else {
-    float s = 0.0f, q = 0.0f;
-    for (int i = 0; i < S; ++i) s += part[((long)i * 2) * D + c], q += part[((long)i * 2 + 1) * D + c];
-    const float dm = s / M, var = fmaxf(q / M - dm * dm, 0.0f);  // dm ~ 0: the shift was the mean
+    const float dm = sums[c] / M, var = fmaxf(sums[D + c] / M - dm * dm, 0.0f);
     stats[D + c] = rsqrtf(var + 1e-5f);
     if (mv) mv[c] = stats[c] + dm, mv[D + c] = var;
   }
 }
 hipError_t launch_bn_stats(const float* c, int M, int D, float* part, float* stats, float* mv, hipStream_t st) {
   const int S = colsum_blocks(M);
+  float* sums = part + (size_t)S * 2 * D;  // [2][D] behind the partials
   hipLaunchKernelGGL(colsum_kernel<false>, dim3(S), dim3(256), 0, st, c, M, D, (const float*)nullptr, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, S, M, D, 0, stats, mv);
+  (void)launch_reduce_leading(part, S, D, D, sums, st);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)sums, M, D, 0, stats, mv);
   hipLaunchKernelGGL(colsum_kernel<true>, dim3(S), dim3(256), 0, st, c, M, D, (const float*)stats, part);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, part, S, M, D, 1, stats, mv);
+  (void)launch_reduce_leading(part, S, (long)2 * D, (long)2 * D, sums, st);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, st, (const float*)sums, M, D, 1, stats, mv);
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void bn_silu_fwd_kernel(const float* __restrict__ c, const float* __restrict__ stats, const float* __restrict__ g,
@@ -556,7 +727,7 @@ hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stat
                               float* dc, int M, int D, hipStream_t st) {
   const int S = colsum_blocks(M);
   hipLaunchKernelGGL(bn_silu_bwd_sums_kernel, dim3(S), dim3(256), 0, st, ds, c, stats, g, b, part, M, D);
-  hipLaunchKernelGGL(reduce_leading_kernel, dim3((2 * D + 255) / 256), dim3(256), 0, st, (const float*)part, S, (long)2 * D, (long)2 * D, sums);
+  (void)launch_reduce_leading(part, S, (long)2 * D, (long)2 * D, sums, st);
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, pw_grid((long)M * D), dim3(256), 0, st, ds, c, stats, g, b, (const float*)sums, dc, (long)M * D, D, 1.0f / M);
   return hipGetLastError();
 }
@@ -585,9 +756,8 @@ hipError_t launch_softmax_fwd(float* S, const int32_t* key_len, int B, int H, in
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void drop_copy_kernel(const float* __restrict__ P, float* __restrict__ Pd, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Pd[i] = P[i] * drop_mul(d, (uint64_t)i, thr, ik);
+  const DropState ds(d);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Pd[i] = P[i] * ds.mul((uint64_t)i);
 }
 hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream_t st) {
   hipLaunchKernelGGL(drop_copy_kernel, pw_grid(n), dim3(256), 0, st, P, Pd, n, d);
@@ -597,14 +767,13 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const DropState ds(d);
   const float* p = P + row * T;
   float* g = dP + row * T;
   float dot = 0.0f;
-  for (int k = lane; k < T; k += 64) dot += g[k] * drop_mul(d, (uint64_t)(row * T + k), thr, ik) * p[k];
+  for (int k = lane; k < T; k += 64) dot += g[k] * ds.mul((uint64_t)(row * T + k)) * p[k];
   dot = wave_sum(dot);
-  for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * drop_mul(d, (uint64_t)(row * T + k), thr, ik) - dot);
+  for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * ds.mul((uint64_t)(row * T + k)) - dot);
 }
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st) {
   const long rows = (long)B * H * T;
@@ -679,11 +848,10 @@ hipError_t launch_col2im_stride2(const float* G, float* dout1, int B, int T1, in
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void add_pe_drop_kernel(float* __restrict__ x, const float* __restrict__ pe, int T, int D, long n, Drop d) {
-  const uint32_t thr = drop_thr(d.p);
-  const float ik = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+  const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const int c = (int)(i % D), t = (int)((i / D) % T);
-    x[i] = (x[i] + pe[(long)t * D + c]) * drop_mul(d, (uint64_t)i, thr, ik);
+    x[i] = (x[i] + pe[(long)t * D + c]) * ds.mul((uint64_t)i);
   }
 }
 hipError_t launch_add_pe_drop(float* x, const float* pe, int B, int T, int D, Drop d, hipStream_t st) {

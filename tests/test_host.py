@@ -125,6 +125,46 @@ def test_world2_gloo_sharded_exit_loss_equals_global_batch():
     assert combined == pytest.approx(full, rel=2e-5, abs=2e-5)
 
 
+def _grad_rank_main(rank, world, port, q):
+    from oracle import conformer_ref as R
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=128, d_model=64, n_head=4)
+        m = R.EarlyConformerRef(**kw).eval()  # running BatchNorm statistics: shards are then independent (per-replica batch
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=0, style="trained"))  # statistics are the documented choice)
+        B, T = 5, 99
+        mel, lens = synth.synth_mel(B, 80, T, seed=0), torch.tensor([99, 90, 80, 99, 70])
+        tgt, tl = synth.synth_targets(B, 8, 256, seed=0)
+        lo, hi = parallel.shard_range(B, rank, world)
+        R.summed_exit_ctc_loss(m(mel[lo:hi], lens[lo:hi]), tgt[lo:hi], tl[lo:hi]).backward()
+        n_coll = parallel.allreduce_gradients(list(m.parameters()), hi - lo, bucket_bytes=100 << 10)
+        if rank == 0:
+            got = [p.grad.clone() for p in m.parameters()]
+            m.zero_grad()
+            R.summed_exit_ctc_loss(m(mel, lens), tgt, tl).backward()
+            err = max(((g - p.grad).abs().max() / (p.grad.abs().max() + 1e-6)).item() for g, p in zip(got, m.parameters()))
+            q.put((n_coll, err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_bucketed_gradient_allreduce_equals_global_batch_gradient():
+    """Config-4 path: per-rank backward on an utterance shard + bucketed, batch-weighted all-reduce == the gradient of the
+    global-batch mean loss."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_grad_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    n_coll, err = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert n_coll >= 3  # the count exchange + more than one bucket
+    assert err < 1e-4
+
+
 def _run_bench(extra_env, *argv):
     import subprocess
     import sys
