@@ -27,12 +27,14 @@ int tfail(int code, const std::string& msg) {
 
 struct Bump {  // bump allocator; base == nullptr: sizes only
   char* base = nullptr;
-  size_t off = 0, peak = 0;
+  size_t off = 0, peak = 0, cap = ~(size_t)0;
+  bool overflow = false;
   float* f(size_t n) {
     off = (off + 255) / 256 * 256;
     float* p = (float*)(base + off);
     off += n * sizeof(float);
     if (off > peak) peak = off;
+    if (off > cap) overflow = true;  // checked by the entry points before anything is reported as done
     return p;
   }
   void reset(size_t to = 0) { off = to; }
@@ -125,11 +127,13 @@ void linear_bwd_weight(Run& r, const float* dy, const float* x, float* dW, float
     g.K = M;
     RUN(launch_gemm(g, r.tr->np, r.st));
   }
-  if (db) {
+  {  // carved whether or not a bias gradient is wanted: the sizing pass runs with null pointers and must see the same layout
     const int nb = colsum_blocks(M);
     float* part = r.scr.f((size_t)nb * N);
-    RUN(launch_colsum_partial(dy, M, N, part, r.st));
-    RUN(launch_reduce_leading(part, nb, N, N, db, r.st));
+    if (db) {
+      RUN(launch_colsum_partial(dy, M, N, part, r.st));
+      RUN(launch_reduce_leading(part, nb, N, N, db, r.st));
+    }
   }
   r.scr.reset(mark);
 }
@@ -454,10 +458,7 @@ int eec_trainer_create(const eec_config* cfg, eec_trainer** out) {
   if (int rc = check_trainer_cfg(*cfg)) return rc;
   eec_trainer* tr = new eec_trainer();
   tr->cfg = *cfg;
-  if (hipError_t e = hipGetDevice(&tr->device); e != hipSuccess) {
-    delete tr;
-    return tfail((int)e, std::string("hipGetDevice: ") + hipGetErrorString(e));
-  }
+  tr->device = -1;  // bound to the device that is current in the first eec_train_forward
   *out = tr;
   return 0;
 }
@@ -486,7 +487,9 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
   if (passes != 1 && passes != 3) return tfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
   if (!(drop_prob >= 0.0f && drop_prob < 1.0f)) return tfail(EEC_ERR_BAD_ARG, "drop_prob in [0, 1)");
   int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev != tr->device) return tfail(EEC_ERR_BAD_ARG, "the trainer belongs to another device");
+  if (hipGetDevice(&dev) != hipSuccess) return tfail(EEC_ERR_BAD_ARG, "no current HIP device");
+  if (tr->device < 0) tr->device = dev;
+  if (dev != tr->device) return tfail(EEC_ERR_BAD_ARG, "the trainer belongs to another device");
   if (int rc = set_geometry(tr, B, T)) return rc;
   if (workspace_bytes < eec_trainer_workspace_bytes(tr, B, T)) return tfail(EEC_ERR_BAD_ARG, "workspace too small");
   tr->np = passes, tr->p = drop_prob, tr->seed = seed, tr->recorded = false;
@@ -500,7 +503,17 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
     tr->tape_bytes = (d.tape.peak + 255) / 256 * 256;
   }
   r.scr.base = (char*)workspace + tr->tape_bytes;
+  r.tape.cap = tr->tape_bytes;
+  if (workspace_bytes < tr->tape_bytes) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  r.scr.cap = workspace_bytes - tr->tape_bytes;
+  {  // the scratch need of this forward, before any launch
+    eec_trainer tmp = *tr;
+    Run d{&tmp, true, nullptr};
+    forward(d, params, mel, lengths, out, bn_batch_stats);
+    if (d.scr.peak > r.scr.cap) return tfail(EEC_ERR_WORKSPACE, "workspace too small for the forward scratch");
+  }
   forward(r, params, mel, lengths, out, bn_batch_stats);
+  if (r.tape.overflow || r.scr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   tr->recorded = true;
   return 0;
@@ -516,8 +529,21 @@ int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_para
   Run r{tr, false, (hipStream_t)stream};
   // the residual-stream gradient is carved from the head of the scratch region through `tape` (kept for the whole backward)
   r.tape.base = (char*)workspace + tr->tape_bytes;
-  r.scr.base = (char*)workspace + tr->tape_bytes + ((size_t)tr->M * tr->cfg.d_model * sizeof(float) + 511) / 256 * 256;
+  const size_t dx_bytes = ((size_t)tr->M * tr->cfg.d_model * sizeof(float) + 511) / 256 * 256;
+  r.scr.base = (char*)workspace + tr->tape_bytes + dx_bytes;
+  if (workspace_bytes < tr->tape_bytes + dx_bytes) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  r.tape.cap = dx_bytes, r.scr.cap = workspace_bytes - tr->tape_bytes - dx_bytes;
+  {  // the scratch need of this backward, before any launch
+    eec_trainer tmp = *tr;
+    Run d{&tmp, true, nullptr};
+    backward(d, params, grads, out, grad_out);
+    if (d.scr.peak > r.scr.cap || d.tape.peak > r.tape.cap)
+      return tfail(EEC_ERR_WORKSPACE, "workspace too small for the backward scratch: need " + std::to_string(d.scr.peak) + " + " +
+                                          std::to_string(d.tape.peak) + ", have " + std::to_string(r.scr.cap) + " + " + std::to_string(r.tape.cap) +
+                                          " (workspace " + std::to_string(workspace_bytes) + ", tape " + std::to_string(tr->tape_bytes) + ")");
+  }
   backward(r, params, grads, out, grad_out);
+  if (r.tape.overflow || r.scr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   return 0;
 }
