@@ -69,7 +69,7 @@ hipError_t launch_glu_bwd(const float* dg, const float* u, float* du, int M, int
 hipError_t launch_dw_fwd(const float* x, const float* w, const float* b, float* y, int B, int T, int D, int K, hipStream_t st);
 hipError_t launch_dw_bwd_data(const float* dy, const float* w, float* dx, int B, int T, int D, int K, hipStream_t st);
 int dw_bwd_weight_blocks(int B, int T);
-hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part /*[blocks][K + 1][D]: taps, then bias*/, float* dw /*[D][K]*/, float* db /*[D]*/,
+hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part /*[blocks + 1][K + 1][D]: taps, then bias*/, float* dw /*[D][K]*/, float* db /*[D]*/,
                                 int B, int T, int D, int K, hipStream_t st);
 
 // BatchNorm1d in train mode + SiLU: stats [2][D] = (batch mean, rstd = 1 / sqrt(biased var + 1e-5)); mv [2][D] = (mean, biased var)
@@ -80,7 +80,8 @@ hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stat
                               float* dc, int M, int D, hipStream_t st);
 
 // P[z][tq][:] = softmax(scale * S[z][tq][:] + (tk >= len[z / H] ? -inf : 0)) in place
-hipError_t launch_softmax_fwd(float* S, const int32_t* key_len, int B, int H, int T, float scale, hipStream_t st);
+// Pd (optional): the dropped copy drop(P) written in the same pass
+hipError_t launch_softmax_fwd(float* S, float* Pd, const int32_t* key_len, int B, int H, int T, float scale, Drop d, hipStream_t st);
 hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream_t st);  // Pd = drop(P)
 // dS = scale * P * (dPd * dropmask - sum_k(dPd * dropmask * P)) in place over dP
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st);

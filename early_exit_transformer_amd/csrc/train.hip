@@ -200,14 +200,10 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
     batched(g, a, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
     RUN(launch_gemm(g, tr->np, r.st));
   }
-  RUN(launch_softmax_fwd(t.P, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), r.st));
   r.scr.reset();
-  const float* Pd = t.P;
-  if (tr->p > 0.0f) {
-    float* pd = r.scr.f((size_t)a.B * a.H * Tq * Tq);
-    RUN(launch_drop_copy(t.P, pd, (long)a.B * a.H * Tq * Tq, drop_of(r, t.site_p), r.st));
-    Pd = pd;
-  }
+  float* pd = r.scr.f((size_t)a.B * a.H * Tq * Tq);  // carved whatever p is: the layout must not depend on the settings
+  const float* Pd = tr->p > 0.0f ? pd : t.P;
+  RUN(launch_softmax_fwd(t.P, tr->p > 0.0f ? pd : nullptr, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
   {  // ctx = Pd . V
     GemmArgs g = gemm_args(Pd, Tq, 1, t.qkv + 2 * D, 1, 3 * D, t.ctx, D, Tq, a.dh, Tq);
     batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.x_b, a.x_h);
@@ -313,9 +309,9 @@ void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, e
   RUN(launch_scale_drop(dx, 1.0f, d_o, (long)M * D, drop_of(r, t.site_res), r.st));
   linear_bwd_weight(r, d_o, t.ctx, (float*)G.attn_out_w, (float*)G.attn_out_b, M, D, D);
   linear_bwd_data(r, d_o, L.attn_out_w, dctx, M, D, D);
+  float* pd = r.scr.f((size_t)np_);  // carved whatever p is
   const float* Pd = t.P;
   if (tr->p > 0.0f) {
-    float* pd = r.scr.f((size_t)np_);
     RUN(launch_drop_copy(t.P, pd, np_, drop_of(r, t.site_p), r.st));
     Pd = pd;
   }
@@ -364,7 +360,7 @@ void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, e
     RUN(hipMemcpyAsync((void*)G.conv_bn_b, sums, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     RUN(hipMemcpyAsync((void*)G.conv_bn_w, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     r.scr.reset(mark);
-    float* wpart = r.scr.f((size_t)dw_bwd_weight_blocks(tr->B, tr->Tq) * (K + 1) * D);
+    float* wpart = r.scr.f((size_t)(dw_bwd_weight_blocks(tr->B, tr->Tq) + 1) * (K + 1) * D);
     RUN(launch_dw_bwd_weight(dc, t.g, wpart, (float*)G.conv_dw_w, (float*)G.conv_dw_b, tr->B, tr->Tq, D, K, r.st));
     r.scr.reset(mark);
   }
@@ -468,7 +464,6 @@ size_t eec_trainer_workspace_bytes(const eec_trainer* tr_in, int B, int T) {
   if (!tr_in) return 0;
   eec_trainer tmp = *tr_in;
   if (set_geometry(&tmp, B, T)) return 0;
-  tmp.p = 0.5f;  // sizes the dropped-probability copies too
   Run r{&tmp, true, nullptr};
   std::vector<eec_layer_params> layers(tmp.cfg.n_exits * tmp.cfg.layers_per_exit);
   std::vector<const float*> heads(tmp.cfg.n_exits, nullptr);

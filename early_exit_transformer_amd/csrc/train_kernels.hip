@@ -15,15 +15,29 @@ constexpr int kLdk = 40;  // bf16 elements per LDS tile row (80 B: the 16 lanes 
 
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
+// wave-wide reductions on the DPP crossbar (no LDS traffic): quad swaps, half-row / row mirrors, then row broadcasts; lane 63
+// holds the total, returned wave-uniform
+#define EECT_DPP_ADD(v, ctrl, rmask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xf, false)))
+#define EECT_DPP_MAX(v, ctrl, rmask) \
+  fmaxf((v), __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (v)), __builtin_bit_cast(int, (v)), ctrl, rmask, 0xf, false)))
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
+  v = EECT_DPP_ADD(v, 0xB1, 0xf);
+  v = EECT_DPP_ADD(v, 0x4E, 0xf);
+  v = EECT_DPP_ADD(v, 0x141, 0xf);
+  v = EECT_DPP_ADD(v, 0x140, 0xf);
+  v = EECT_DPP_ADD(v, 0x142, 0xa);
+  v = EECT_DPP_ADD(v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-  return v;
+  v = EECT_DPP_MAX(v, 0xB1, 0xf);
+  v = EECT_DPP_MAX(v, 0x4E, 0xf);
+  v = EECT_DPP_MAX(v, 0x141, 0xf);
+  v = EECT_DPP_MAX(v, 0x140, 0xf);
+  v = EECT_DPP_MAX(v, 0x142, 0xa);
+  v = EECT_DPP_MAX(v, 0x143, 0xc);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -337,14 +351,16 @@ hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kLnMax = 16;  // elements per lane: D <= 1024
 
+// NE = elements per lane (D <= 64 * NE): one wave per row
+template <int NE>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
                                                      float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int M, int D) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (long)row * D;
-  float v[kLnMax], s = 0.0f;
+  float v[NE], s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kLnMax; ++i) {
+  for (int i = 0; i < NE; ++i) {
     const int c = lane + 64 * i;
     v[i] = c < D ? xr[c] : 0.0f;
     s += v[i];
@@ -352,14 +368,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const float mu = wave_sum(s) / D;
   float q = 0.0f;
 #pragma unroll
-  for (int i = 0; i < kLnMax; ++i) {
+  for (int i = 0; i < NE; ++i) {
     const int c = lane + 64 * i;
     const float d = c < D ? v[i] - mu : 0.0f;
     q += d * d;
   }
   const float rs = rsqrtf(wave_sum(q) / D + 1e-5f);
 #pragma unroll
-  for (int i = 0; i < kLnMax; ++i) {
+  for (int i = 0; i < NE; ++i) {
     const int c = lane + 64 * i;
     if (c < D) y[(long)row * D + c] = (v[i] - mu) * rs * g[c] + b[c];
   }
@@ -367,49 +383,50 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int M, int D, hipStream_t st) {
   if (D > 64 * kLnMax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, g, b, y, mean, rstd, M, D);
+  const dim3 grid((M + 3) / 4);
+  if (D <= 256) hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, dim3(256), 0, st, x, g, b, y, mean, rstd, M, D);
+  else if (D <= 512) hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, dim3(256), 0, st, x, g, b, y, mean, rstd, M, D);
+  else hipLaunchKernelGGL(ln_fwd_kernel<16>, grid, dim3(256), 0, st, x, g, b, y, mean, rstd, M, D);
   return hipGetLastError();
 }
 
 int ln_bwd_blocks(int M) { return max(1, min(1024, (M + 7) / 8)); }
+template <int NE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ part, int M, int D) {
-  __shared__ float red[4][2][64 * kLnMax];
+  __shared__ float red[4][2][64 * NE];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
-  float gam[kLnMax], dg[kLnMax], db[kLnMax];
+  float gam[NE], dg[NE], db[NE];
 #pragma unroll
-  for (int i = 0; i < kLnMax; ++i) {
+  for (int i = 0; i < NE; ++i) {
     const int c = lane + 64 * i;
     gam[i] = c < D ? g[c] : 0.0f, dg[i] = 0.0f, db[i] = 0.0f;
   }
   for (int row = r_begin + w; row < r_end; row += 4) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[kLnMax], dyv[kLnMax], c1 = 0.0f, c2 = 0.0f;
+    float xh[NE], dyv[NE], rv[NE], c1 = 0.0f, c2 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < kLnMax; ++i) {
+    for (int i = 0; i < NE; ++i) {
       const int c = lane + 64 * i;
       const bool ok = c < D;
       xh[i] = ok ? (x[(long)row * D + c] - mu) * rs : 0.0f;
       dyv[i] = ok ? dy[(long)row * D + c] : 0.0f;
+      rv[i] = (ok && dres) ? dres[(long)row * D + c] : 0.0f;
       const float t = dyv[i] * gam[i];
       c1 += t, c2 += t * xh[i];
       dg[i] += dyv[i] * xh[i], db[i] += dyv[i];
     }
     c1 = wave_sum(c1) / D, c2 = wave_sum(c2) / D;
 #pragma unroll
-    for (int i = 0; i < kLnMax; ++i) {
+    for (int i = 0; i < NE; ++i) {
       const int c = lane + 64 * i;
-      if (c < D) {
-        float v = rs * (dyv[i] * gam[i] - c1 - xh[i] * c2);
-        if (dres) v += dres[(long)row * D + c];
-        dx[(long)row * D + c] = v;
-      }
+      if (c < D) dx[(long)row * D + c] = rs * (dyv[i] * gam[i] - c1 - xh[i] * c2) + rv[i];
     }
   }
 #pragma unroll
-  for (int i = 0; i < kLnMax; ++i) red[w][0][lane + 64 * i] = dg[i], red[w][1][lane + 64 * i] = db[i];
+  for (int i = 0; i < NE; ++i) red[w][0][lane + 64 * i] = dg[i], red[w][1][lane + 64 * i] = db[i];
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     part[((long)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
@@ -419,7 +436,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const float* mean, const float* rstd, const float* dres,
                          float* dx, float* part, int M, int D, hipStream_t st) {
   if (D > 64 * kLnMax) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_blocks(M)), dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+  const dim3 grid(ln_bwd_blocks(M));
+  if (D <= 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+  else if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+  else hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
   return hipGetLastError();
 }
 
@@ -640,21 +660,22 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
     part[((long)blockIdx.x * (K + 1) + K) * D + d] = acc[kDwMaxK];
   }
 }
-// dw[d][j] = sum_s part[s][j][d], db[d] = sum_s part[s][K][d]
-__global__ __launch_bounds__(256) void dw_weight_finalize_kernel(const float* __restrict__ part, int S, int D, int K, float* __restrict__ dw, float* __restrict__ db) {
+// dw[d][j] = tot[j][d], db[d] = tot[K][d]  (tot = the partials summed over the blocks, [K + 1][D])
+__global__ __launch_bounds__(256) void dw_weight_finalize_kernel(const float* __restrict__ tot, int D, int K, float* __restrict__ dw, float* __restrict__ db) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= (K + 1) * D) return;
   const int j = i / D, d = i % D;
-  float s = 0.0f;
-  for (int b = 0; b < S; ++b) s += part[((long)b * (K + 1) + j) * D + d];
-  if (j < K) dw[(long)d * K + j] = s;
-  else db[d] = s;
+  if (j < K) dw[(long)d * K + j] = tot[i];
+  else db[d] = tot[i];
 }
 hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part, float* dw, float* db, int B, int T, int D, int K, hipStream_t st) {
   if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
   const int S = dw_bwd_weight_blocks(B, T);
+  const long n = (long)(K + 1) * D;
+  float* tot = part + (size_t)S * n;  // [K + 1][D] behind the partials
   hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(S), dim3(256), 0, st, dy, x, part, T, D, K);
-  hipLaunchKernelGGL(dw_weight_finalize_kernel, dim3(((K + 1) * D + 255) / 256), dim3(256), 0, st, (const float*)part, S, D, K, dw, db);
+  (void)launch_reduce_leading(part, S, n, n, tot, st);
+  hipLaunchKernelGGL(dw_weight_finalize_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)tot, D, K, dw, db);
   return hipGetLastError();
 }
 
@@ -735,24 +756,63 @@ hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stat
 // ---------------------------------------------------------------------------------------------------------------------
 // softmax over keys (one wave per query row)
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, const int32_t* __restrict__ key_len, long rows, int H, int T, float scale) {
+constexpr int kSmMax = 16;  // keys per lane held in registers: T <= 1024 (longer rows take the re-reading kernel)
+// one wave per query row; REG: the row lives in registers between the three passes.  Pd (optional) = drop(P)
+template <bool REG>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, float* __restrict__ Pd, const int32_t* __restrict__ key_len, long rows,
+                                                          int H, int T, float scale, Drop d) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const DropState ds(d);
   const int len = key_len[row / ((long)H * T)];
   float* s = S + row * T;
+  float v[kSmMax];
   float mx = -INFINITY;
-  for (int k = lane; k < T; k += 64) mx = fmaxf(mx, k < len ? s[k] * scale : -INFINITY);
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < kSmMax; ++i) {
+      const int k = lane + 64 * i;
+      v[i] = (k < T && k < len) ? s[k] * scale : -INFINITY;
+      mx = fmaxf(mx, v[i]);
+    }
+  } else {
+    for (int k = lane; k < T; k += 64) mx = fmaxf(mx, k < len ? s[k] * scale : -INFINITY);
+  }
   mx = wave_max(mx);
   float sum = 0.0f;
-  for (int k = lane; k < T; k += 64) sum += k < len ? __expf(s[k] * scale - mx) : 0.0f;
-  sum = wave_sum(sum);
-  const float inv = 1.0f / sum;  // len == 0: 0 * inf = nan in every column, as torch
-  for (int k = lane; k < T; k += 64) s[k] = k < len ? __expf(s[k] * scale - mx) * inv : (len > 0 ? 0.0f : NAN);
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < kSmMax; ++i) {
+      v[i] = __expf(v[i] - mx);  // exp(-inf) = 0 for masked keys; len == 0: exp(nan)
+      sum += (lane + 64 * i < T) ? v[i] : 0.0f;
+    }
+  } else {
+    for (int k = lane; k < T; k += 64) sum += k < len ? __expf(s[k] * scale - mx) : 0.0f;
+  }
+  const float inv = 1.0f / wave_sum(sum);  // len == 0: nan in every column, as torch
+  if (REG) {
+#pragma unroll
+    for (int i = 0; i < kSmMax; ++i) {
+      const int k = lane + 64 * i;
+      if (k < T) {
+        const float p = len > 0 ? v[i] * inv : NAN;
+        s[k] = p;
+        if (Pd) Pd[row * T + k] = p * ds.mul((uint64_t)(row * T + k));
+      }
+    }
+  } else {
+    for (int k = lane; k < T; k += 64) {
+      const float p = k < len ? __expf(s[k] * scale - mx) * inv : (len > 0 ? 0.0f : NAN);
+      s[k] = p;
+      if (Pd) Pd[row * T + k] = p * ds.mul((uint64_t)(row * T + k));
+    }
+  }
 }
-hipError_t launch_softmax_fwd(float* S, const int32_t* key_len, int B, int H, int T, float scale, hipStream_t st) {
+hipError_t launch_softmax_fwd(float* S, float* Pd, const int32_t* key_len, int B, int H, int T, float scale, Drop d, hipStream_t st) {
   const long rows = (long)B * H * T;
-  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, key_len, rows, H, T, scale);
+  if (T <= 64 * kSmMax) hipLaunchKernelGGL(softmax_fwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, Pd, key_len, rows, H, T, scale, d);
+  else hipLaunchKernelGGL(softmax_fwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, Pd, key_len, rows, H, T, scale, d);
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void drop_copy_kernel(const float* __restrict__ P, float* __restrict__ Pd, long n, Drop d) {
@@ -763,6 +823,7 @@ hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream
   hipLaunchKernelGGL(drop_copy_kernel, pw_grid(n), dim3(256), 0, st, P, Pd, n, d);
   return hipGetLastError();
 }
+template <bool REG>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP, long rows, int T, float scale, Drop d) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -771,13 +832,31 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   const float* p = P + row * T;
   float* g = dP + row * T;
   float dot = 0.0f;
-  for (int k = lane; k < T; k += 64) dot += g[k] * ds.mul((uint64_t)(row * T + k)) * p[k];
-  dot = wave_sum(dot);
-  for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * ds.mul((uint64_t)(row * T + k)) - dot);
+  if (REG) {
+    float pv[kSmMax], gv[kSmMax];
+#pragma unroll
+    for (int i = 0; i < kSmMax; ++i) {
+      const int k = lane + 64 * i;
+      pv[i] = k < T ? p[k] : 0.0f;
+      gv[i] = k < T ? g[k] * ds.mul((uint64_t)(row * T + k)) : 0.0f;
+      dot += gv[i] * pv[i];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int i = 0; i < kSmMax; ++i) {
+      const int k = lane + 64 * i;
+      if (k < T) g[k] = scale * pv[i] * (gv[i] - dot);
+    }
+  } else {
+    for (int k = lane; k < T; k += 64) dot += g[k] * ds.mul((uint64_t)(row * T + k)) * p[k];
+    dot = wave_sum(dot);
+    for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * ds.mul((uint64_t)(row * T + k)) - dot);
+  }
 }
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st) {
   const long rows = (long)B * H * T;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T, scale, d);
+  if (T <= 64 * kSmMax) hipLaunchKernelGGL(softmax_bwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T, scale, d);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T, scale, d);
   return hipGetLastError();
 }
 
