@@ -327,7 +327,7 @@ def main():
         d = (time.perf_counter() - t1) / n3
         f3, _ = flops_per_forward(B, T, D=512, L=3)
         config3 = {"workload": f"early_conformer ctc 18-layer d_model=512 (6 exits x 3, 8 heads x 64), batch {B}, mel [80 x {T}], "
-                               "forward + fused per-exit CTC losses (BASELINE.json configs[2] geometry; no backward yet)",
+                               "forward + fused per-exit CTC losses (BASELINE.json configs[2] geometry, inference path; the training step of this geometry is train_step.config3_bf16)",
                    "value": round(B * T / d, 1), "unit": "mel-frames/s", "ms_per_step": round(d * 1e3, 4),
                    "algorithmic_flop_per_forward": f3, "frac_of_mfma_peak": round(f3 / d / MFMA_PEAK_FLOPS, 4),
                    "precision_mode": args.precision}

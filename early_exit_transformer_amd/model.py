@@ -267,8 +267,9 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         """First slice of the training path (train.py:53-70): the exit heads ``linears.*`` are trainable on a FROZEN
         encoder.  The encoder stack runs on the HIP path without autograd, in eval semantics (running BatchNorm
         statistics, no dropout) whatever ``self.training`` says; the heads are an autograd function over its taps, so
-        ``exit_ctc_losses(model(src, lengths), ...).sum().backward()`` fills ``linears.*.grad``.  A trainable parameter
-        anywhere else still raises: the encoder's own backward is not built."""
+        ``exit_ctc_losses(model(src, lengths), ...).sum().backward()`` fills ``linears.*.grad``.  With a trainable parameter
+        anywhere else ``Early_conformer.forward`` takes the full training step instead (``_forward_train``); the classes that
+        reuse this method (Splitformer, Early_zipformer, full_conformer) still raise for those."""
         trainable = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("linears.")]
         if trainable:
             raise NotImplementedError("only the exit heads (linears.*) can be trained yet: freeze the encoder "
