@@ -73,6 +73,8 @@ def compare_grads(got, want, tol, label):
 
 @pytest.mark.parametrize("cfg,B,T,lens", [
     (SMALL, 3, 131, [131, 90, 57]),
+    (SMALL, 2, 151, [151, 100]),  # T' = 37: odd frame count -> the GEMMs' element-wise edge paths
+    (dict(SMALL, n_head=2, depthwise_kernel_size=31, d_feed_forward=96), 5, 79, [79, 79, 60, 41, 30]),  # head dim 32, T' = 19
     (dict(n_enc_exits=2, n_enc_layers=1, d_feed_forward=512), 2, 259, [259, 170]),
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=2, d_feed_forward=256, depthwise_kernel_size=31), 2, 99, [99, 64]),
 ])
