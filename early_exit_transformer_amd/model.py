@@ -83,6 +83,12 @@ class _HipEncoderMixin:
                 capi.load().eec_encoder_destroy(enc)
             except Exception:
                 pass
+        tr = getattr(self, "_trainer", None)
+        if tr is not None:
+            try:
+                capi.load().eec_trainer_destroy(tr)
+            except Exception:
+                pass
 
     # -- packing ------------------------------------------------------------
     def _param_tensors(self) -> List[Tensor]:
