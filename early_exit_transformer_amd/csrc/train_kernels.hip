@@ -180,6 +180,20 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* __restrict__ t, int rbas
   return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// f(IntTag<0>{}), ..., f(IntTag<N - 1>{}): a loop whose index is a compile-time constant in the body (register arrays indexed by
+// it never fall back to scratch memory, whatever the unroller decides)
+template <int I>
+struct IntTag {
+  static constexpr int value = I;
+};
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(IntTag<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
 template <bool V>
 struct FastTag {
   static constexpr bool value = V;
@@ -192,10 +206,14 @@ template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
-  __shared__ __attribute__((aligned(16))) bf16 a_hi[TileGeo<BM>::kElems];
-  __shared__ __attribute__((aligned(16))) bf16 a_lo[NP == 3 ? TileGeo<BM>::kElems : 8];
-  __shared__ __attribute__((aligned(16))) bf16 b_hi[TileGeo<BN>::kElems];
-  __shared__ __attribute__((aligned(16))) bf16 b_lo[NP == 3 ? TileGeo<BN>::kElems : 8];
+  // one LDS block: the operand planes during the k-loop, a [32][BN + 4] fp32 slab of the output tile in the epilogue
+  constexpr int EA = TileGeo<BM>::kElems, EB = TileGeo<BN>::kElems, kSlabLd = BN + 4;
+  constexpr int kPlaneBytes = (NP == 3 ? 2 : 1) * (EA + EB) * 2, kSlabBytes = 32 * kSlabLd * 4;
+  __shared__ __attribute__((aligned(16))) char smem[kPlaneBytes > kSlabBytes ? kPlaneBytes : kSlabBytes];
+  bf16* a_hi = (bf16*)smem;
+  bf16* b_hi = a_hi + EA;
+  bf16* a_lo = NP == 3 ? b_hi + EB : a_hi;
+  bf16* b_lo = NP == 3 ? a_lo + EA : b_hi;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
   const int z0 = blockIdx.z / g.zdiv, z1 = blockIdx.z % g.zdiv;
   const float* __restrict__ A = g.A + z0 * g.a_z0 + z1 * g.a_z1;
@@ -224,10 +242,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   // dimensions the rows of a k-contiguous tile all fall on the same few L2 / HBM channels for a given k offset, and
   // workgroups in lockstep would all hit those at once (measured: 101 -> TFLOP/s class of the transposed layouts)
   const int rot = (int)((blockIdx.x * 3 + blockIdx.y + blockIdx.z) % (unsigned)nk);
-  auto k_of = [&](int kt) { const int t = kt + rot; return (t >= nk ? t - nk : t) * kBK; };
+  auto k_of = [&](int kt) __attribute__((always_inline)) { const int t = kt + rot; return (t >= nk ? t - nk : t) * kBK; };
   // fast: every tile of both operands is a full, aligned interior tile -- the loop then carries no bounds logic at all
   const bool fast = la.clean && lb.clean && (K % kBK) == 0;
-  auto load_ab = [&](float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], int k0, auto fast_tag) {
+  auto load_ab = [&](float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], int k0, auto fast_tag) __attribute__((always_inline)) {
     if (decltype(fast_tag)::value) {
       la.load_fast(ra, k0);
       lb.load_fast(rb, k0);
@@ -236,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       lb.load(rb, k0, K, tid);
     }
   };
-  auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) {
+  auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
     store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
     store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
     __syncthreads();
@@ -267,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     }
     __syncthreads();
   };
-  auto k_loop = [&](auto fast_tag) {
+  auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
     load_ab(ra0, rb0, k_of(0), fast_tag);
     if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
     for (int kt = 0; kt < nk; kt += 2) {
@@ -277,40 +295,83 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   };
   if (fast) k_loop(FastTag<true>{});
   else k_loop(FastTag<false>{});
-  // epilogue: the values an element needs from memory (old C, aux) are gathered per 32x32 block before any store
+  // epilogue: the output tile leaves through LDS in slabs of 32 rows, so that every thread stores 16 contiguous bytes of a row
+  // (an accumulator lane holds single columns: direct stores are 4-byte stores, four times as many instructions) and the
+  // epilogue arithmetic runs on float4s.  The k-loop ended with a barrier: the planes are dead.
   const DropState ds(g.drop);
   const float* __restrict__ aux = g.aux;
   float* __restrict__ C2 = g.C2;
+  float* slab = (float*)smem;
+  const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
+  static_for<0, BM / 32>([&](auto sl_tag) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_tag)::value;
+    constexpr int NPS = 32 * (BN / 4) / 256;
+    // what the slab's elements need from memory (old C, aux) is requested first: in flight across the LDS hand-over
+    f32x4 oldv[NPS], auxv[NPS];
+    if (cvec) {
 #pragma unroll
-  for (int mt = 0; mt < TM; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < TN; ++nt) {
-      const int n = n0 + (wn * TN + nt) * 32 + (lane & 31);
-      if (n >= g.N) continue;
-      const float bias = g.bias ? g.bias[n] : 0.0f;
-      const int mb = m0 + (wm * TM + mt) * 32;
-      float old[16], ax[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = mb + acc_row(i, lane);
+      for (int ps = 0; ps < NPS; ++ps) {
+        const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+        const int m = m0 + sl * 32 + row, n = n0 + c4;
+        const bool ok = m < g.M && n < g.N;
         const long ci = (long)m * g.c_m + n;
-        old[i] = (g.accumulate && m < g.M) ? C[ci] : 0.0f;
-        ax[i] = (g.epi == EPI_DSILU && m < g.M) ? aux[ci] : 0.0f;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int m = mb + acc_row(i, lane);
-        if (m >= g.M) continue;
-        const long ci = (long)m * g.c_m + n;
-        float v = g.alpha * acc[mt][nt][i] + bias + old[i];
-        if (g.epi == EPI_DSILU) {
-          const float sg = 1.0f / (1.0f + __expf(-ax[i]));
-          v *= ds.mul((uint64_t)ci) * sg * (1.0f + ax[i] * (1.0f - sg));
-        }
-        C[ci] = v;
-        if (g.epi == EPI_SILU) C2[ci] = v / (1.0f + __expf(-v)) * ds.mul((uint64_t)ci);
+        oldv[ps] = (g.accumulate && ok) ? *(const f32x4*)(C + ci) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        auxv[ps] = (g.epi == EPI_DSILU && ok) ? *(const f32x4*)(aux + ci) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
       }
     }
+    if (wm == sl / TM) {
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) slab[acc_row(i, lane) * kSlabLd + (wn * TN + nt) * 32 + (lane & 31)] = acc[sl % TM][nt][i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const int m = m0 + sl * 32 + row, n = n0 + c4;
+      if (m < g.M && n < g.N) {
+        const f32x4 a4 = *(const f32x4*)(slab + row * kSlabLd + c4);
+        const long ci = (long)m * g.c_m + n;
+        const int nvalid = min(4, g.N - n);
+        float v[4], v2[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = g.alpha * a4[j] + ((g.bias && j < nvalid) ? g.bias[n + j] : 0.0f);
+        if (cvec) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += oldv[ps][j];
+          if (g.epi == EPI_DSILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float x = auxv[ps][j], sg = 1.0f / (1.0f + __expf(-x));
+              v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
+            }
+          }
+          *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
+          if (g.epi == EPI_SILU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v2[j] = v[j] / (1.0f + __expf(-v[j])) * ds.mul((uint64_t)(ci + j));
+            *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (j < nvalid) {
+              float t = v[j];
+              if (g.accumulate) t += C[ci + j];
+              if (g.epi == EPI_DSILU) {
+                const float x = aux[ci + j], sg = 1.0f / (1.0f + __expf(-x));
+                t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
+              }
+              C[ci + j] = t;
+              if (g.epi == EPI_SILU) C2[ci + j] = t / (1.0f + __expf(-t)) * ds.mul((uint64_t)(ci + j));
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  });
 }
 
 template <int TM, int TN, int WGM, int WGN>
