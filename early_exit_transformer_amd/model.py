@@ -252,9 +252,13 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
     train_passes = 3  # training GEMMs: 3 = bf16 hi/lo split, three MFMA products (~fp32 results); 1 = plain bf16 operands
 
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
-        if self.training and torch.is_grad_enabled():
-            if type(self) is Early_conformer and any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("linears.")):
+        if self.training and type(self) is Early_conformer:
+            # train-mode semantics (batch-statistics BatchNorm, dropout) whenever the module is in train mode -- with or
+            # without autograd, as the reference; the one exception is the frozen-encoder case below
+            if not torch.is_grad_enabled() or any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("linears.")):
                 return self._forward_train(src, lengths)
+            return self._forward_heads_trainable(src, lengths)
+        if self.training and torch.is_grad_enabled():
             return self._forward_heads_trainable(src, lengths)
         return self._run_encoder(src, lengths)[0]
 
@@ -744,6 +748,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         model, names = ctx.model, ctx.names
         if ctx.generation != model._train_generation:

@@ -261,7 +261,9 @@ int eec_frontend_forward(eec_frontend* fe, const float* wave, const int64_t* len
  * keeps it untouched until eec_train_backward); one recorded forward per trainer at a time.
  * eec_train_backward: `out` = the log-probs eec_train_forward returned, `grad_out` = dLoss/d out [E,B,T',V]; `grads` is
  * an eec_params whose pointers are WRITTEN (overwritten, not accumulated) with the gradient of the parameter at the same
- * position (pe / running_mean / running_var entries are ignored).  Gradient with respect to `mel` is not produced. */
+ * position (pe / running_mean / running_var entries are ignored).  Gradient with respect to `mel` is not produced.
+ * A trainer is bound to the device that is current in its first eec_train_forward (eec_trainer_workspace_bytes is host
+ * arithmetic and needs none), is not thread-safe, and holds ONE recorded forward at a time. */
 typedef struct eec_trainer eec_trainer;
 const char* eec_trainer_last_error(void);
 int eec_trainer_create(const eec_config* cfg, eec_trainer** out);

@@ -158,6 +158,24 @@ def test_dropout_masks_are_consistent_between_forward_and_backward():
         assert abs(fd - an) < 0.05 * max(abs(an), abs(fd)) + 2e-3, n
 
 
+def test_train_mode_without_autograd_keeps_train_semantics():
+    """model.train() under torch.no_grad() (the reference would still use batch statistics and dropout): same output as the
+    autograd forward with the same seed, different from eval mode."""
+    kw = base_kwargs(n_enc_exits=1, n_enc_layers=1, d_feed_forward=256)
+    _, gpu = make_train_pair(kw, seed=3, drop=0.1)
+    mel, lens = synth.synth_mel(2, 80, 99, seed=3).cuda(), torch.tensor([99, 70])
+    torch.manual_seed(4)
+    with_grad = gpu(mel, lens).detach()
+    torch.manual_seed(4)
+    with torch.no_grad():
+        without = gpu(mel, lens)
+    assert torch.equal(with_grad, without) and not without.requires_grad
+    gpu.eval()
+    with torch.no_grad():
+        ev = gpu(mel, lens)
+    assert (ev - without).abs().max().item() > 1e-3
+
+
 def test_reference_training_loop_reduces_the_loss():
     """The loop of train.py:27-75 (AdamW, clip_grad_norm_, summed per-exit CTC loss) on the product module."""
     kw = base_kwargs(**SMALL)
