@@ -202,8 +202,10 @@ struct FastTag {
 // epilogue variants: C = v;  EPI_SILU: also C2 = drop(silu(v));  EPI_DSILU: C = v * dropmask * silu'(aux)
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2 };
 
-template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+// STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
+// contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
+template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES>
+__global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   // one LDS block: the operand planes during the k-loop, a [32][BN + 4] fp32 slab of the output tile in the epilogue
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
     store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
     __syncthreads();
-    if (kt + 2 < nk) load_ab(ra, rb, k_of(kt + 2), fast_tag);
+    if (kt + STAGES < nk) load_ab(ra, rb, k_of(kt + STAGES), fast_tag);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -287,10 +289,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   };
   auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
     load_ab(ra0, rb0, k_of(0), fast_tag);
-    if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
-    for (int kt = 0; kt < nk; kt += 2) {
-      k_tile(kt, ra0, rb0, fast_tag);
-      if (kt + 1 < nk) k_tile(kt + 1, ra1, rb1, fast_tag);
+    if constexpr (STAGES == 1) {
+      for (int kt = 0; kt < nk; ++kt) k_tile(kt, ra0, rb0, fast_tag);
+    } else {
+      if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
+      for (int kt = 0; kt < nk; kt += 2) {
+        k_tile(kt, ra0, rb0, fast_tag);
+        if (kt + 1 < nk) k_tile(kt + 1, ra1, rb1, fast_tag);
+      }
     }
   };
   if (fast) k_loop(FastTag<true>{});
@@ -379,7 +385,10 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nz);
   const bool akc = g.a_k == 1, bkc = g.b_k == 1;
-#define EECT_GEMM(NP, AK, BK) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK>), grid, dim3(256), 0, st, g)
+#ifndef EECT_STAGES
+#define EECT_STAGES 1  // measured on one box, default model: 1 -> 38.9 ms per step, 2 -> 40.6 ms, 2 for >= 32 k-tiles only -> 39.8 ms
+#endif
+#define EECT_GEMM(NP, AK, BK) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES>), grid, dim3(256), 0, st, g)
   if (np == 1) {
     if (akc && bkc) EECT_GEMM(1, true, true);
     else if (akc) EECT_GEMM(1, true, false);
