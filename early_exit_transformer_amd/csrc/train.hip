@@ -45,7 +45,7 @@ struct FfnTape {
   uint32_t site_act, site_res;
 };
 struct AttnTape {
-  float *x, *ln, *mean, *rstd, *qkv, *P, *ctx;
+  float *x, *ln, *mean, *rstd, *qkv, *P, *Pd, *ctx;  // Pd: drop(P), kept for the backward (== P when drop_prob is 0)
   uint32_t site_p, site_res;
 };
 struct ConvTape {
@@ -144,8 +144,7 @@ void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const floa
   const int nb = ln_bwd_blocks(M);
   float* part = r.scr.f((size_t)nb * 2 * D);
   RUN(launch_ln_bwd(dln, x, g, mean, rstd, add_res ? dx : nullptr, dx, part, M, D, r.st));
-  RUN(launch_reduce_leading(part, nb, 2 * D, D, dg, r.st));
-  RUN(launch_reduce_leading(part + D, nb, 2 * D, D, db, r.st));
+  RUN(launch_reduce_leading2(part, nb, D, dg, db, r.st));
   r.scr.reset(mark);
 }
 
@@ -192,6 +191,8 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
   const int M = tr->M, D = a.D, Tq = a.Tq;
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.qkv = r.tape.f((size_t)M * 3 * D);
   t.P = r.tape.f((size_t)a.B * a.H * Tq * Tq), t.ctx = r.tape.f((size_t)M * D);
+  float* pd = r.tape.f((size_t)a.B * a.H * Tq * Tq);  // carved whatever drop_prob is: the layout must not depend on the settings
+  t.Pd = tr->p > 0.0f ? pd : t.P;
   t.site_p = r.site++, t.site_res = r.site++;
   RUN(launch_ln_fwd(x, L.attn_ln_w, L.attn_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
   linear_fwd(r, t.ln, L.attn_in_w, L.attn_in_b, t.qkv, M, 3 * D, D);
@@ -201,9 +202,8 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
     RUN(launch_gemm(g, tr->np, r.st));
   }
   r.scr.reset();
-  float* pd = r.scr.f((size_t)a.B * a.H * Tq * Tq);  // carved whatever p is: the layout must not depend on the settings
-  const float* Pd = tr->p > 0.0f ? pd : t.P;
-  RUN(launch_softmax_fwd(t.P, tr->p > 0.0f ? pd : nullptr, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
+  const float* Pd = t.Pd;
+  RUN(launch_softmax_fwd(t.P, tr->p > 0.0f ? t.Pd : nullptr, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
   {  // ctx = Pd . V
     GemmArgs g = gemm_args(Pd, Tq, 1, t.qkv + 2 * D, 1, 3 * D, t.ctx, D, Tq, a.dh, Tq);
     batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.x_b, a.x_h);
@@ -309,12 +309,7 @@ void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, e
   RUN(launch_scale_drop(dx, 1.0f, d_o, (long)M * D, drop_of(r, t.site_res), r.st));
   linear_bwd_weight(r, d_o, t.ctx, (float*)G.attn_out_w, (float*)G.attn_out_b, M, D, D);
   linear_bwd_data(r, d_o, L.attn_out_w, dctx, M, D, D);
-  float* pd = r.scr.f((size_t)np_);  // carved whatever p is
-  const float* Pd = t.P;
-  if (tr->p > 0.0f) {
-    RUN(launch_drop_copy(t.P, pd, np_, drop_of(r, t.site_p), r.st));
-    Pd = pd;
-  }
+  const float* Pd = t.Pd;
   {  // dV[tk][d] = sum_tq Pd[tq][tk] dctx[tq][d]
     GemmArgs g = gemm_args(Pd, 1, Tq, dctx, 1, D, dqkv + 2 * D, 3 * D, Tq, a.dh, Tq);
     batched(g, a, a.p_b, a.p_h, a.x_b, a.x_h, a.qkv_b, a.qkv_h);

@@ -515,7 +515,8 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const 
 
 // out[j] = sum_s part[s * stride + j]: SL partial sums per column in flight (256 / SL columns per block), summed through LDS
 template <int SL>
-__global__ __launch_bounds__(256) void reduce_leading_kernel(const float* __restrict__ part, int S, long stride, long n, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void reduce_leading_kernel(const float* __restrict__ part, int S, long stride, long n, float* __restrict__ out,
+                                                             float* __restrict__ out1, long n0) {
   constexpr int COLS = 256 / SL;
   __shared__ float red[SL][COLS];
   const int c = threadIdx.x % COLS, sl = threadIdx.x / COLS;
@@ -535,12 +536,18 @@ __global__ __launch_bounds__(256) void reduce_leading_kernel(const float* __rest
     float t = 0.0f;
 #pragma unroll
     for (int k = 0; k < SL; ++k) t += red[k][c];
-    out[j] = t;
+    if (out1 && j >= n0) out1[j - n0] = t;  // two-output form: columns [n0, n) go to the second array
+    else out[j] = t;
   }
 }
 hipError_t launch_reduce_leading(const float* part, int S, long stride, long n, float* out, hipStream_t st) {
-  if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, S, stride, n, out);
-  else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, stride, n, out);
+  if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, S, stride, n, out, (float*)nullptr, 0L);
+  else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, stride, n, out, (float*)nullptr, 0L);
+  return hipGetLastError();
+}
+hipError_t launch_reduce_leading2(const float* part, int S, long n, float* out0, float* out1, hipStream_t st) {
+  if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((2 * n + 63) / 64)), dim3(256), 0, st, part, S, 2 * n, 2 * n, out0, out1, n);
+  else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((2 * n + 15) / 16)), dim3(256), 0, st, part, S, 2 * n, 2 * n, out0, out1, n);
   return hipGetLastError();
 }
 
