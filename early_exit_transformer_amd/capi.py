@@ -57,6 +57,26 @@ class EecParams(C.Structure):
                 ("head_w", C.POINTER(C.c_void_p)), ("head_b", C.POINTER(C.c_void_p))]
 
 
+class EecDecoderLayerParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("sa_in_w", "sa_in_b", "sa_out_w", "sa_out_b", "ca_in_w", "ca_in_b", "ca_out_w", "ca_out_b",
+                                          "w1", "b1", "w2", "b2", "norm1_w", "norm1_b", "norm2_w", "norm2_b", "norm3_w", "norm3_b")]
+
+
+# field -> state_dict key suffix below ``decoders.{e}.layers.{l}.``
+DECODER_LAYER_KEYS = {"sa_in_w": "self_attn.in_proj_weight", "sa_in_b": "self_attn.in_proj_bias",
+                      "sa_out_w": "self_attn.out_proj.weight", "sa_out_b": "self_attn.out_proj.bias",
+                      "ca_in_w": "multihead_attn.in_proj_weight", "ca_in_b": "multihead_attn.in_proj_bias",
+                      "ca_out_w": "multihead_attn.out_proj.weight", "ca_out_b": "multihead_attn.out_proj.bias",
+                      "w1": "linear1.weight", "b1": "linear1.bias", "w2": "linear2.weight", "b2": "linear2.bias",
+                      "norm1_w": "norm1.weight", "norm1_b": "norm1.bias", "norm2_w": "norm2.weight", "norm2_b": "norm2.bias",
+                      "norm3_w": "norm3.weight", "norm3_b": "norm3.bias"}
+
+
+class EecDecoderParams(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("pe", C.c_void_p), ("layers", C.POINTER(EecDecoderLayerParams)), ("n_layers", C.c_int32),
+                ("max_len", C.c_int32), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
+
+
 EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
            "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy",
@@ -66,7 +86,8 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_ctc_beam_workspace_bytes", "eec_ctc_beam_decode",
            "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward",
            "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
-           "eec_train_forward", "eec_train_backward", "eec_train_gemm"]
+           "eec_train_forward", "eec_train_backward", "eec_train_gemm",
+           "eec_decoder_last_error", "eec_decoder_workspace_bytes", "eec_decoder_forward"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -136,6 +157,11 @@ def load() -> C.CDLL:
                                        C.c_size_t, C.c_void_p]
     lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
+    lib.eec_decoder_last_error.restype = C.c_char_p
+    lib.eec_decoder_workspace_bytes.argtypes = [C.c_int] * 7
+    lib.eec_decoder_workspace_bytes.restype = C.c_size_t
+    lib.eec_decoder_forward.argtypes = [C.POINTER(EecDecoderParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     _lib = lib

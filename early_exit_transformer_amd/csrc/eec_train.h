@@ -32,7 +32,7 @@ struct GemmArgs {
   float alpha;
   const float* bias;
   int accumulate;
-  // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux)
+  // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux); 3: C = max(C, 0)
   int epi;
   float* C2;
   const float* aux;
@@ -89,6 +89,13 @@ hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st);
 
 hipError_t launch_logsoftmax_fwd(const float* logits, float* logp, int M, int V, hipStream_t st);
+
+// AED decoder helpers (decoder.hip).  P[z][tq][:] = softmax(scale * S[z][tq][:] + mask) in place over [B*H][Tq][Tk] scores:
+// key tk is masked for query tq of batch b = z / H when (causal && tk > tq) || (key_pad && key_pad[b * Tk + tk])
+hipError_t launch_softmax_masked(float* S, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad, hipStream_t st);
+// x[i][:] = emb[tok[i]][:] + pe[i % S][:];  pad[i] = (tok[i] == pad_idx)
+hipError_t launch_embed_pe(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
+                           int pad_idx, hipStream_t st);
 
 // stem helpers: im2col of the first conv (mel [B][C][T] -> [B*T1][C*3], column c*3 + j = mel[b][c][2*t1 + j]);
 // [O][C][3] <-> [O][3][C] weight permutes; gather of the second conv's input gradient from G [B*T2][3][D]

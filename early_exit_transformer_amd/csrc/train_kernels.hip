@@ -200,7 +200,7 @@ struct FastTag {
 };
 
 // epilogue variants: C = v;  EPI_SILU: also C2 = drop(silu(v));  EPI_DSILU: C = v * dropmask * silu'(aux)
-enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2 };
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3 };
 
 // STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
 // contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
@@ -353,6 +353,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
               v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
             }
           }
+          if (g.epi == EPI_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+          }
           *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
           if (g.epi == EPI_SILU) {
 #pragma unroll
@@ -369,6 +373,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
                 const float x = aux[ci + j], sg = 1.0f / (1.0f + __expf(-x));
                 t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
               }
+              if (g.epi == EPI_RELU) t = fmaxf(t, 0.0f);
               C[ci + j] = t;
               if (g.epi == EPI_SILU) C2[ci + j] = t / (1.0f + __expf(-t)) * ds.mul((uint64_t)(ci + j));
             }
@@ -951,6 +956,47 @@ __global__ __launch_bounds__(256) void logsoftmax_fwd_kernel(const float* __rest
 }
 hipError_t launch_logsoftmax_fwd(const float* logits, float* logp, int M, int V, hipStream_t st) {
   hipLaunchKernelGGL(logsoftmax_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, logits, logp, M, V);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// AED decoder helpers
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_masked_kernel(float* __restrict__ S, long rows, int H, int Tq, int Tk, float scale, int causal,
+                                                             const unsigned char* __restrict__ key_pad) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int tq = (int)(row % Tq);
+  const long b = row / ((long)H * Tq);
+  const unsigned char* pad = key_pad ? key_pad + b * Tk : nullptr;
+  float* s = S + row * Tk;
+  auto live = [&](int k) { return !(causal && k > tq) && !(pad && pad[k]); };
+  float mx = -INFINITY;
+  for (int k = lane; k < Tk; k += 64) mx = fmaxf(mx, live(k) ? s[k] * scale : -INFINITY);
+  mx = wave_max(mx);
+  float sum = 0.0f;
+  for (int k = lane; k < Tk; k += 64) sum += live(k) ? __expf(s[k] * scale - mx) : 0.0f;
+  const float inv = 1.0f / wave_sum(sum);  // no live key: nan in every column, as torch
+  for (int k = lane; k < Tk; k += 64) s[k] = live(k) ? __expf(s[k] * scale - mx) * inv : (mx == -INFINITY ? NAN : 0.0f);
+}
+hipError_t launch_softmax_masked(float* S, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad, hipStream_t st) {
+  const long rows = (long)B * H * Tq;
+  hipLaunchKernelGGL(softmax_masked_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, H, Tq, Tk, scale, causal, key_pad);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void embed_pe_kernel(const long long* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe,
+                                                       float* __restrict__ x, unsigned char* __restrict__ pad, long n_tok, int S, int D, int V, int pad_idx) {
+  const long i = blockIdx.x;
+  if (i >= n_tok) return;
+  const long long t = tok[i];
+  const long long tc = t < 0 ? 0 : (t >= V ? V - 1 : t);  // nn.Embedding would raise; stay in bounds
+  if (threadIdx.x == 0 && pad) pad[i] = t == pad_idx;
+  for (int c = threadIdx.x; c < D; c += 256) x[i * D + c] = emb[tc * D + c] + pe[(i % S) * D + c];
+}
+hipError_t launch_embed_pe(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
+                           int pad_idx, hipStream_t st) {
+  hipLaunchKernelGGL(embed_pe_kernel, dim3((unsigned)n_tok), dim3(256), 0, st, tok, emb, pe, x, pad, n_tok, S, D, V, pad_idx);
   return hipGetLastError();
 }
 

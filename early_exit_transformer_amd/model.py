@@ -773,8 +773,9 @@ class _EncoderTrainFn(torch.autograd.Function):
 
 
 class full_conformer(_HipEncoderMixin, nn.Module):
-    """AED model: HIP encoder (this repo's scope) + the reference's PyTorch attention decoder
-    (``nn.TransformerDecoder`` stays on PyTorch-ROCm)."""
+    """AED model: HIP encoder + the attention decoder.  Inference (``_decoder_``, ``forward`` without autograd) runs the
+    decoder on the hand-written path too (csrc/decoder.hip); with autograd the decoder is the reference's
+    ``nn.TransformerDecoder`` on PyTorch-ROCm (its parameters are the same tensors either way)."""
 
     _head_attr = "linears_1"
     _pe_attr = "positional_encoder_1"
@@ -812,16 +813,73 @@ class full_conformer(_HipEncoderMixin, nn.Module):
         n = int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits  # reference loop
         return self._run_encoder(src, lengths, want_out=False, want_x=True, n_groups=n)[2]
 
-    def _decode_one(self, trg: Tensor, enc: Tensor, idx: int) -> Tensor:
+    decoder_passes = 3  # the HIP decoder's GEMM operands: 3 = bf16 hi/lo split (~1e-5 of fp32), 1 = plain bf16
+
+    def _decode_one(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool = False) -> Tensor:
+        if trg.is_cuda and not (self.training and torch.is_grad_enabled()):
+            return self._hip_decoder(trg, enc, idx, log_softmax)  # inference: the hand-written path (csrc/decoder.hip)
+        # training with autograd: the reference's own modules on PyTorch-ROCm (the decoder's backward is not built)
         sz = trg.size(1)
         tgt_mask = torch.triu(torch.full((sz, sz), float("-inf"), device=trg.device), diagonal=1)
         pad_mask = trg == self.trg_pad_idx
         t = self.positional_encoder_2(self.emb(trg))
-        return self.linears_2[idx](self.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=pad_mask))
+        out = self.linears_2[idx](self.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=pad_mask))
+        return torch.log_softmax(out, dim=2) if log_softmax else out
+
+    def _hip_decoder(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool) -> Tensor:
+        """``linears_2[idx](decoders[idx](positional_encoder_2(emb(trg)), enc, causal + padding masks))`` in eval semantics
+        through eec_decoder_forward; trg int64 [Bm, S], enc fp32 [Bm, T', D] -> [Bm, S, V] logits or log-probs."""
+        lib = capi.load()
+        dev = trg.device
+        cfg = self._cfg
+        Bm, S = trg.shape
+        Tq = enc.size(1)
+        if enc.size(0) != Bm or enc.size(2) != cfg.d_model:
+            raise ValueError(f"enc must be [{Bm}, T', {cfg.d_model}], got {tuple(enc.shape)}")
+        dec = self.decoders[idx]
+        tensors = [self.emb.weight, self.positional_encoder_2.pe, self.layer_norm.weight, self.layer_norm.bias,
+                   self.linears_2[idx].weight, self.linears_2[idx].bias] + list(dec.layers.parameters())
+        key = (dev, tuple(t.data_ptr() for t in tensors))
+        cache = self.__dict__.setdefault("_dec_cache", {})
+        ent = cache.get(idx)
+        if ent is None or ent[0] != key:
+            for t in tensors:
+                if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise RuntimeError(f"decoder parameters must be contiguous fp32 tensors on {dev}")
+            layers = (capi.EecDecoderLayerParams * len(dec.layers))()
+            for l, layer in enumerate(dec.layers):
+                sd = dict(layer.named_parameters())
+                for field, name in capi.DECODER_LAYER_KEYS.items():
+                    setattr(layers[l], field, sd[name].data_ptr())
+            ps = capi.EecDecoderParams(self.emb.weight.data_ptr(), self.positional_encoder_2.pe.data_ptr(), layers, len(dec.layers),
+                                       self.positional_encoder_2.pe.size(0), self.layer_norm.weight.data_ptr(),
+                                       self.layer_norm.bias.data_ptr(), self.linears_2[idx].weight.data_ptr(),
+                                       self.linears_2[idx].bias.data_ptr())
+            ent = (key, ps, layers)
+            cache[idx] = ent
+        ps = ent[1]
+        layer0 = dec.layers[0]
+        d_ff, V = layer0.linear1.out_features, self.linears_2[idx].out_features
+        with torch.cuda.device(dev):
+            trg_c = trg.to(torch.int64).contiguous()
+            enc_c = enc.contiguous().float()
+            nbytes = lib.eec_decoder_workspace_bytes(cfg.d_model, cfg.n_heads, d_ff, V, Bm, S, Tq)
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+            out = torch.empty((Bm, S, V), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.eec_decoder_forward(C.byref(ps), cfg.d_model, cfg.n_heads, d_ff, V, int(self.trg_pad_idx), trg_c.data_ptr(),
+                                         enc_c.data_ptr(), Bm, S, Tq, int(self.decoder_passes), int(log_softmax), out.data_ptr(),
+                                         ws_ptr, nbytes, C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_forward failed (code {rc}): {lib.eec_decoder_last_error().decode(errors='replace')}")
+            for t in (ws, trg_c, enc_c):
+                t.record_stream(torch.cuda.current_stream(dev))
+        return out
 
     def _decoder_(self, trg: Tensor, enc: Tensor, layer_n: int) -> Tensor:
         idx = (int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits) - 1
-        return torch.log_softmax(self._decode_one(trg, enc, idx), dim=2)
+        return self._decode_one(trg, enc, idx, log_softmax=True)
 
     def forward(self, src: Tensor, lengths: Tensor, trg: Tensor):
         enc_out, taps, _ = self._run_encoder(src, lengths, want_taps=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 11
+#define EEC_ABI_VERSION 12
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -277,6 +277,35 @@ int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_para
 /* C = alpha * A . B^T (+ bias) on the training GEMM (test hook): A [M][K], B [N][K], C [M][N] fp32 row-major on the device */
 int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
                    int b_transposed, void* stream);
+
+/* ---- AED decoder forward (full_conformer._decoder_, early_exit.py:739-762; util/beam_infer.py:236-240) ----------------
+ * out[Bm][S][V] = (log_softmax of) linears_2[e]( TransformerDecoder_e( positional_encoder_2(emb(trg)), memory = enc ) ) in eval
+ * mode: n_layers x nn.TransformerDecoderLayer(batch_first, norm_first: causal + target-padding self-attention,
+ * cross-attention over enc [Bm][Tq][D], ReLU feed-forward) and the shared final LayerNorm.  fp32 parameters are read in
+ * place (state_dict tensors); arithmetic as the training GEMM (passes 3: bf16 hi/lo split, ~1e-5 of fp32).  trg: int64
+ * [Bm][S]; positions equal to pad_idx are masked as keys.  The caller's beam search (util/beam_infer.py:198-307) stays
+ * above this call: one call per decoding step, as the reference (no KV cache). */
+typedef struct eec_decoder_layer_params {
+  const float *sa_in_w, *sa_in_b;   /* self_attn.in_proj_{weight,bias}      [3D,D],[3D] */
+  const float *sa_out_w, *sa_out_b; /* self_attn.out_proj.{weight,bias}     [D,D],[D]   */
+  const float *ca_in_w, *ca_in_b;   /* multihead_attn.in_proj_{weight,bias}             */
+  const float *ca_out_w, *ca_out_b; /* multihead_attn.out_proj.{weight,bias}            */
+  const float *w1, *b1, *w2, *b2;   /* linear1 [F,D],[F]; linear2 [D,F],[D]             */
+  const float *norm1_w, *norm1_b, *norm2_w, *norm2_b, *norm3_w, *norm3_b;
+} eec_decoder_layer_params;
+typedef struct eec_decoder_params {
+  const float* emb;                       /* emb.weight [V,D]                                   */
+  const float* pe;                        /* positional_encoder_2.pe [max_len,1,D]              */
+  const eec_decoder_layer_params* layers; /* HOST array of n_layers: decoders.e.layers.l        */
+  int32_t n_layers, max_len;
+  const float *norm_w, *norm_b;           /* layer_norm.{weight,bias} (shared final norm)       */
+  const float *head_w, *head_b;           /* linears_2.e.{weight,bias} [V,D],[V]                */
+} eec_decoder_params;
+const char* eec_decoder_last_error(void);
+size_t eec_decoder_workspace_bytes(int d_model, int n_heads, int d_ff, int vocab, int Bm, int S, int Tq);
+int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* trg,
+                        const float* enc, int Bm, int S, int Tq, int passes, int log_softmax, float* out, void* workspace,
+                        size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

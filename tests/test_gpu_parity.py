@@ -41,7 +41,7 @@ def run_gpu(model, mel, lens, prec="f16f8"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 11
+    assert lib.eec_abi_version() == 12
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
@@ -516,8 +516,7 @@ def test_encoder_lengths_bit_exact():
 
 def test_aed_greedy_tokens_golden():
     """BASELINE config 5 substitute: greedy (beam = 1) AED decode for EVERY exit, B = 1, default 6 x 2 model
-    with 6 decoder layers, as inference.py:44-51 drives it: ``_encoder_`` on the HIP path, ``_decoder_`` (the reference's
-    nn.TransformerDecoder) on PyTorch-ROCm.  Fixture: the reference's own full_conformer run on CPU.  Tokens must be
+    with 6 decoder layers, as inference.py:44-51 drives it: ``_encoder_`` and ``_decoder_`` both on the HIP path.  Fixture: the reference's own full_conformer run on CPU.  Tokens must be
     identical up to the first step whose top-2 margin in the fixture is below the safety margin."""
     import os
     import sys
@@ -552,9 +551,45 @@ def test_aed_greedy_tokens_golden():
     assert compared >= 0.8 * total, f"only {compared}/{total} decode steps had safe margins"
 
 
+def test_hip_decoder_matches_the_reference_decoder_modules():
+    """full_conformer._decoder_ on the hand-written path (eec_decoder_forward) against the same parameters run through the
+    reference's own modules (nn.TransformerDecoder, norm_first, causal + padding masks) in fp32 on the CPU: log-probs within
+    2e-5 of their scale (bf16x3 GEMMs), for ragged targets with PAD positions, several beams, S = 1 and odd T'."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=256, n_head=8, d_feed_forward=512, depthwise_kernel_size=31, dec_voc_size=256)
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=3, **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, 5), strict=True)
+    g = torch.Generator().manual_seed(0)
+    for Bm, S, Tq in ((1, 1, 17), (4, 9, 33), (10, 23, 64)):
+        enc = torch.randn(Bm, Tq, 256, generator=g)
+        trg = torch.randint(3, 256, (Bm, S), generator=g)
+        trg[:, 0] = 1
+        if S > 4:
+            trg[0, S - 2:] = 126  # PAD tail on one row (masked as keys)
+        fc = fc.cpu()
+        with torch.no_grad():
+            want = [fc._decoder_(trg, enc, n) for n in (1, 2)]
+            want_logits = fc._decode_one(trg, enc, 0)
+        fc = fc.cuda()
+        with torch.no_grad():
+            got = [fc._decoder_(trg.cuda(), enc.cuda(), n).cpu() for n in (1, 2)]
+            got_logits = fc._decode_one(trg.cuda(), enc.cuda(), 0).cpu()
+        for w, gt in zip(want + [want_logits], got + [got_logits]):
+            ok = torch.isfinite(w)
+            assert torch.equal(ok, torch.isfinite(gt))
+            # bf16x3 GEMMs are good to ~1e-5 RELATIVE: the synthetic decoder's log-probs reach -40 (measured error 2e-4 there)
+            tol = 2e-5 * max(10.0, w[ok].abs().max().item())
+            assert (w[ok] - gt[ok]).abs().max().item() < tol, (Bm, S, Tq, (w[ok] - gt[ok]).abs().max().item(), tol)
+
+
 def test_aed_beam_search_golden():
-    """inference.py:18-62 (evaluate_batch_ae) end to end on the product: ONE HIP encoder run for all exits, the reference's
-    nn.TransformerDecoder on PyTorch-ROCm, BeamInference.beam_search (beam 10) on the device.  Fixture: the reference's
+    """inference.py:18-62 (evaluate_batch_ae) end to end on the product: ONE HIP encoder run for all exits, the HIP
+    decoder (eec_decoder_forward) per step, BeamInference.beam_search (beam 10) on the device.  Fixture: the reference's
     full_conformer on CPU driven by its beam-search algorithm restated with its own loops (make_golden.aed_beam_search).
     Candidates near the beam boundary can swap under 1e-3 log-prob noise, so the final scores are compared as sorted
     values, and the best token sequence wherever its score leads the runner-up by a safe margin."""
