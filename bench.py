@@ -334,6 +334,35 @@ def main():
         del m3
         torch.cuda.empty_cache()
 
+    # ---- AED inference (BASELINE.json configs[4] substitute; secondary line): evaluate_batch_ae of inference.py:18-62 for one
+    # synthetic utterance -- ONE HIP encoder run for all exits, then beam search (beam 10) per exit with the HIP decoder ----
+    aed = None
+    if rank == 0 and world == 1 and not args.no_modes:
+        try:
+            from early_exit_transformer_amd.beam import BeamInference
+            from early_exit_transformer_amd.model import full_conformer
+            fc = full_conformer(trg_pad_idx=126, n_dec_layers=6, device=dev, **{k: v for k, v in CFG.items() if k != "src_pad_idx"}).eval()
+            fc.load_state_dict(synth.synth_state_dict(fc.state_dict(), seed=4, style="init"))
+            fc = fc.to(dev)
+            spec, vlen = mel[0], torch.tensor(T)
+            inf = BeamInference()
+            kw5 = dict(vocab_size=CFG["dec_voc_size"], SOS_token=1, EOS_token=2, PAD_token=126, pen_alpha=1.0)
+            inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hyps = inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t1
+            steps5 = int(T / 12)
+            aed = {"workload": f"full_conformer (6 x 2 encoder, 6 decoder layers per exit), 1 utterance of {T} mel frames: encoder once, "
+                               f"beam search (beam 10, {steps5} steps) for each of the 6 exits, decoder on eec_decoder_forward",
+                   "seconds_per_utterance": round(d, 4), "decoder_steps": 6 * steps5, "ms_per_decoder_step": round(d / (6 * steps5) * 1e3, 3),
+                   "tokens_out": [len(h) for h in hyps]}
+            del fc
+            torch.cuda.empty_cache()
+        except Exception as e:  # a secondary line never takes the headline down
+            aed = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     # ---- mel front end: waveform -> [B, 80, T] power mel for the same batch (secondary line) ----
     frontend = None
     if rank == 0 and world == 1 and not args.no_modes:
@@ -482,7 +511,7 @@ def main():
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
             "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3, "frontend": frontend,
-            "train_step": train,
+            "train_step": train, "aed_decode": aed,
         }
         print(json.dumps(line), flush=True)
     if dist is not None:
