@@ -78,6 +78,10 @@ struct DropState {
 //   one 8-byte store -- and read back through ds_read_b64_tr_b16, the hardware transpose: a 16-lane group reads a
 //   4 (k) x 16 (rows) block and every lane receives the 4 k-values of its row.  ldt = R + 32 (R for R = 32) puts the four
 //   k-rows of a block on disjoint bank quarters.
+// row of a k-contiguous tile that thread group g (8 threads = the 32 k of one row) owns: neighbouring groups take rows 4 apart,
+// so that the two rows a 16-lane ds_write_b64 group stores (80-byte row stride) fall on disjoint halves of the 32 write banks
+__device__ __forceinline__ int kc_row(int g) { return (g & ~7) | ((g & 1) << 2) | ((g >> 1) & 3); }
+
 template <int R>
 struct TileGeo {
   static constexpr int kLdt = R == 32 ? 32 : R + 32;
@@ -105,7 +109,7 @@ struct TileLoader {
     for (int it = 0; it < R / 32; ++it) {
       const int idx = it * 256 + tid;
       if (KC) {
-        const int r = r0 + (idx >> 3);
+        const int r = r0 + kc_row(idx >> 3);
         nv[it] = r < Rmax ? 4 : 0;
         p[it] = X + (long)min(r, Rmax - 1) * s_r + (idx & 7) * 4;  // clamped: always a readable row
         off[it] = (uint32_t)(p[it] - X);
@@ -163,7 +167,7 @@ __device__ __forceinline__ void store_tile(bf16* __restrict__ hi, bf16* __restri
     const bf16x4 h = __builtin_convertvector(x, bf16x4);
     bf16x4 l;
     if (NP == 3) l = __builtin_convertvector(x - __builtin_convertvector(h, f32x4), bf16x4);
-    const int off = KC ? (idx >> 3) * kLdk + (idx & 7) * 4 : (idx / (R / 4)) * TileGeo<R>::kLdt + (idx % (R / 4)) * 4;
+    const int off = KC ? kc_row(idx >> 3) * kLdk + (idx & 7) * 4 : (idx / (R / 4)) * TileGeo<R>::kLdt + (idx % (R / 4)) * 4;
     *(bf16x4*)(hi + off) = h;
     if (NP == 3) *(bf16x4*)(lo + off) = l;
   }

@@ -52,6 +52,19 @@ def test_trainer_workspace_sizing_runs_without_a_device(lib):
         lib.eec_trainer_destroy(h)
 
 
+def test_decoder_workspace_sizing_and_argument_checks(lib):
+    """eec_decoder_workspace_bytes is host arithmetic; eec_decoder_forward rejects bad arguments before touching a device."""
+    import ctypes as C
+    n1 = lib.eec_decoder_workspace_bytes(256, 8, 2048, 256, 10, 5, 256)
+    n2 = lib.eec_decoder_workspace_bytes(256, 8, 2048, 256, 10, 50, 256)
+    assert 0 < n1 < n2
+    assert lib.eec_decoder_workspace_bytes(256, 7, 2048, 256, 10, 5, 256) == 0  # d_model not divisible by the heads
+    assert lib.eec_decoder_workspace_bytes(256, 8, 2048, 256, 0, 5, 256) == 0
+    ps = capi.EecDecoderParams()
+    rc = lib.eec_decoder_forward(C.byref(ps), 256, 8, 2048, 256, 126, None, None, 1, 1, 1, 3, 1, None, None, 0, None)
+    assert rc != 0 and b"null" in lib.eec_decoder_last_error()
+
+
 def test_out_frames_matches_conv_arithmetic(lib):
     for T in (7, 8, 10, 11, 131, 1027, 2051, 8003):
         t1 = (T - 3) // 2 + 1
