@@ -90,6 +90,16 @@ hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, fl
 
 hipError_t launch_logsoftmax_fwd(const float* logits, float* logp, int M, int V, hipStream_t st);
 
+// Fused self-attention of the training step (train_attention.hip; head dim 32 or 64): qkv [B*Tq][3D] (in_proj output),
+// ctx / d_ctx [B*Tq][D], lse / delta [B*H][Tq] (row log-sum-exp kept for the backward; delta is scratch), dqkv [B*Tq][3D].
+// No [B, H, Tq, Tq] tensor exists; the backward recomputes the probabilities.  Dropout stream positions are those of the
+// flat [B*H][Tq][Tq] probability tensor.
+bool attn_fused_supported(int D, int H);
+hipError_t launch_attn_fwd_fused(const float* qkv, const int32_t* key_len, float* ctx, float* lse, int B, int H, int Tq, int D, int np, Drop d,
+                                 hipStream_t st);
+hipError_t launch_attn_bwd_fused(const float* qkv, const int32_t* key_len, const float* ctx, const float* d_ctx, const float* lse, float* delta,
+                                 float* dqkv, int B, int H, int Tq, int D, int np, Drop d, hipStream_t st);
+
 // AED decoder helpers (decoder.hip).  P[z][tq][:] = softmax(scale * S[z][tq][:] + mask) in place over [B*H][Tq][Tk] scores:
 // key tk is masked for query tq of batch b = z / H when (causal && tk > tq) || (key_pad && key_pad[b * Tk + tk])
 hipError_t launch_softmax_masked(float* S, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad, hipStream_t st);

@@ -46,6 +46,7 @@ struct FfnTape {
 };
 struct AttnTape {
   float *x, *ln, *mean, *rstd, *qkv, *P, *Pd, *ctx;  // Pd: drop(P), kept for the backward (== P when drop_prob is 0)
+  float* lse;                                         // fused path (head dim 32 / 64): row log-sum-exp instead of P / Pd
   uint32_t site_p, site_res;
 };
 struct ConvTape {
@@ -189,25 +190,35 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
   const eec_trainer* tr = r.tr;
   const AttnGeo a = attn_geo(tr);
   const int M = tr->M, D = a.D, Tq = a.Tq;
+  const bool fused = attn_fused_supported(D, a.H);  // a property of the configuration: the sizing pass carves the same way
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.qkv = r.tape.f((size_t)M * 3 * D);
-  t.P = r.tape.f((size_t)a.B * a.H * Tq * Tq), t.ctx = r.tape.f((size_t)M * D);
-  float* pd = r.tape.f((size_t)a.B * a.H * Tq * Tq);  // carved whatever drop_prob is: the layout must not depend on the settings
-  t.Pd = tr->p > 0.0f ? pd : t.P;
+  t.ctx = r.tape.f((size_t)M * D);
+  t.P = t.Pd = t.lse = nullptr;
+  if (fused) {
+    t.lse = r.tape.f((size_t)a.B * a.H * Tq);
+  } else {
+    t.P = r.tape.f((size_t)a.B * a.H * Tq * Tq);
+    float* pd = r.tape.f((size_t)a.B * a.H * Tq * Tq);  // carved whatever drop_prob is: the layout must not depend on the settings
+    t.Pd = tr->p > 0.0f ? pd : t.P;
+  }
   t.site_p = r.site++, t.site_res = r.site++;
   RUN(launch_ln_fwd(x, L.attn_ln_w, L.attn_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
   linear_fwd(r, t.ln, L.attn_in_w, L.attn_in_b, t.qkv, M, 3 * D, D);
-  {  // S = Q . K^T
-    GemmArgs g = gemm_args(t.qkv, 3 * D, 1, t.qkv + D, 3 * D, 1, t.P, Tq, Tq, Tq, a.dh);
-    batched(g, a, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
-    RUN(launch_gemm(g, tr->np, r.st));
-  }
   r.scr.reset();
-  const float* Pd = t.Pd;
-  RUN(launch_softmax_fwd(t.P, tr->p > 0.0f ? t.Pd : nullptr, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
-  {  // ctx = Pd . V
-    GemmArgs g = gemm_args(Pd, Tq, 1, t.qkv + 2 * D, 1, 3 * D, t.ctx, D, Tq, a.dh, Tq);
-    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.x_b, a.x_h);
-    RUN(launch_gemm(g, tr->np, r.st));
+  if (fused) {
+    RUN(launch_attn_fwd_fused(t.qkv, tr->key_len, t.ctx, t.lse, a.B, a.H, Tq, D, tr->np, drop_of(r, t.site_p), r.st));
+  } else {
+    {  // S = Q . K^T
+      GemmArgs g = gemm_args(t.qkv, 3 * D, 1, t.qkv + D, 3 * D, 1, t.P, Tq, Tq, Tq, a.dh);
+      batched(g, a, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
+    RUN(launch_softmax_fwd(t.P, tr->p > 0.0f ? t.Pd : nullptr, tr->key_len, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
+    {  // ctx = Pd . V
+      GemmArgs g = gemm_args(t.Pd, Tq, 1, t.qkv + 2 * D, 1, 3 * D, t.ctx, D, Tq, a.dh, Tq);
+      batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.x_b, a.x_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
   }
   float* o = r.scr.f((size_t)M * D);
   linear_fwd(r, t.ctx, L.attn_out_w, L.attn_out_b, o, M, D, D);
@@ -301,35 +312,40 @@ void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, e
   const AttnGeo a = attn_geo(tr);
   const int M = tr->M, D = a.D, Tq = a.Tq;
   const long np_ = (long)a.B * a.H * Tq * Tq;
+  const bool fused = attn_fused_supported(D, a.H);
   r.scr.reset();
   float* d_o = r.scr.f((size_t)M * D);
   float* dctx = r.scr.f((size_t)M * D);
   float* dqkv = r.scr.f((size_t)M * 3 * D);
-  float* dP = r.scr.f((size_t)np_);
+  float* dP = fused ? r.scr.f((size_t)a.B * a.H * Tq) : r.scr.f((size_t)np_);  // fused: the per-row delta instead
   RUN(launch_scale_drop(dx, 1.0f, d_o, (long)M * D, drop_of(r, t.site_res), r.st));
   linear_bwd_weight(r, d_o, t.ctx, (float*)G.attn_out_w, (float*)G.attn_out_b, M, D, D);
   linear_bwd_data(r, d_o, L.attn_out_w, dctx, M, D, D);
-  const float* Pd = t.Pd;
-  {  // dV[tk][d] = sum_tq Pd[tq][tk] dctx[tq][d]
-    GemmArgs g = gemm_args(Pd, 1, Tq, dctx, 1, D, dqkv + 2 * D, 3 * D, Tq, a.dh, Tq);
-    batched(g, a, a.p_b, a.p_h, a.x_b, a.x_h, a.qkv_b, a.qkv_h);
-    RUN(launch_gemm(g, tr->np, r.st));
-  }
-  {  // dPd[tq][tk] = sum_d dctx[tq][d] V[tk][d]
-    GemmArgs g = gemm_args(dctx, D, 1, t.qkv + 2 * D, 3 * D, 1, dP, Tq, Tq, Tq, a.dh);
-    batched(g, a, a.x_b, a.x_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
-    RUN(launch_gemm(g, tr->np, r.st));
-  }
-  RUN(launch_softmax_bwd(t.P, dP, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
-  {  // dQ[tq][d] = sum_tk dS[tq][tk] K[tk][d]
-    GemmArgs g = gemm_args(dP, Tq, 1, t.qkv + D, 1, 3 * D, dqkv, 3 * D, Tq, a.dh, Tq);
-    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
-    RUN(launch_gemm(g, tr->np, r.st));
-  }
-  {  // dK[tk][d] = sum_tq dS[tq][tk] Q[tq][d]
-    GemmArgs g = gemm_args(dP, 1, Tq, t.qkv, 1, 3 * D, dqkv + D, 3 * D, Tq, a.dh, Tq);
-    batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
-    RUN(launch_gemm(g, tr->np, r.st));
+  if (fused) {
+    RUN(launch_attn_bwd_fused(t.qkv, tr->key_len, t.ctx, dctx, t.lse, dP, dqkv, a.B, a.H, Tq, D, tr->np, drop_of(r, t.site_p), r.st));
+  } else {
+    const float* Pd = t.Pd;
+    {  // dV[tk][d] = sum_tq Pd[tq][tk] dctx[tq][d]
+      GemmArgs g = gemm_args(Pd, 1, Tq, dctx, 1, D, dqkv + 2 * D, 3 * D, Tq, a.dh, Tq);
+      batched(g, a, a.p_b, a.p_h, a.x_b, a.x_h, a.qkv_b, a.qkv_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
+    {  // dPd[tq][tk] = sum_d dctx[tq][d] V[tk][d]
+      GemmArgs g = gemm_args(dctx, D, 1, t.qkv + 2 * D, 3 * D, 1, dP, Tq, Tq, Tq, a.dh);
+      batched(g, a, a.x_b, a.x_h, a.qkv_b, a.qkv_h, a.p_b, a.p_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
+    RUN(launch_softmax_bwd(t.P, dP, a.B, a.H, Tq, 1.0f / sqrtf((float)a.dh), drop_of(r, t.site_p), r.st));
+    {  // dQ[tq][d] = sum_tk dS[tq][tk] K[tk][d]
+      GemmArgs g = gemm_args(dP, Tq, 1, t.qkv + D, 1, 3 * D, dqkv, 3 * D, Tq, a.dh, Tq);
+      batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
+    {  // dK[tk][d] = sum_tq dS[tq][tk] Q[tq][d]
+      GemmArgs g = gemm_args(dP, 1, Tq, t.qkv, 1, 3 * D, dqkv + D, 3 * D, Tq, a.dh, Tq);
+      batched(g, a, a.p_b, a.p_h, a.qkv_b, a.qkv_h, a.qkv_b, a.qkv_h);
+      RUN(launch_gemm(g, tr->np, r.st));
+    }
   }
   linear_bwd_weight(r, dqkv, t.ln, (float*)G.attn_in_w, (float*)G.attn_in_b, M, 3 * D, D);
   linear_bwd_data(r, dqkv, L.attn_in_w, d_o, M, 3 * D, D);  // d_o now holds d LN-output

@@ -1,0 +1,366 @@
+// Fused self-attention of the training step (head dim 32 or 64): forward without the [B, H, T', T'] score / probability
+// tensors in HBM -- a wave owns 32 query frames, walks the key tiles with an online softmax and keeps only the row
+// log-sum-exp for the backward -- and a backward in two passes that recompute the probabilities from Q, K and that
+// log-sum-exp: one over query tiles (dQ), one over key tiles (dK, dV).  Operands are read as fp32 from the packed
+// in_proj output [M][3D] and split into bf16 hi / lo in registers (3 MFMA products per contraction, or 1: eec_train.h).
+//
+// Orientation trick (as the inference kernel): score tiles are computed TRANSPOSED where the next product contracts over
+// their rows, so that an accumulator lane already holds what the next MFMA wants as its operand: accumulator register i
+// of lane half h is tile row 16*(i/8) + 8*((i%8)/4) + 4*h + i%4, i.e. registers 8*ks .. 8*ks+7 are the eight k-slots of
+// k-step ks; the partner operand is gathered from memory with the same slot -> row map.
+#include "eec_train.h"
+
+namespace eect {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct DropState2 {  // same generator as train_kernels.hip (kept in sync by tests: fused and unfused paths must agree)
+  uint32_t key, thr;
+  float inv_keep;
+  bool on;
+  __device__ __forceinline__ explicit DropState2(const Drop& d) {
+    uint64_t x = d.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)d.site << 32 | d.site);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    key = (uint32_t)(x >> 32) ^ (uint32_t)x;
+    const double t = (double)d.p * 4294967296.0;
+    thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+    inv_keep = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
+    on = d.p > 0.0f;
+  }
+  __device__ __forceinline__ float mul(uint64_t i) const {
+    if (!on) return 1.0f;
+    uint32_t h = (uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + key;
+    h ^= h >> 16, h *= 0x7FEB352Du, h ^= h >> 15, h *= 0x846CA68Bu, h ^= h >> 16;
+    return h >= thr ? inv_keep : 0.0f;
+  }
+};
+
+struct Frag {
+  bf16x8 hi, lo;
+};
+template <int NP>
+__device__ __forceinline__ Frag split8(const f32x8 v) {
+  Frag f;
+  f.hi = __builtin_convertvector(v, bf16x8);
+  if (NP == 3) f.lo = __builtin_convertvector(v - __builtin_convertvector(f.hi, f32x8), bf16x8);
+  else f.lo = f.hi;
+  return f;
+}
+// c += a . b with the operands' bf16 hi / lo parts
+template <int NP>
+__device__ __forceinline__ f32x16 mfma3(const Frag& a, const Frag& b, f32x16 c) {
+  if (NP == 3) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// tile row of k-slot j (0..7) of k-step ks (0, 1) for lane half hh: the accumulator layout read as an operand
+__device__ __forceinline__ int slot_row(int ks, int j, int hh) { return 16 * ks + 8 * (j >> 2) + 4 * hh + (j & 3); }
+__device__ __forceinline__ int acc_row(int i, int hh) { return (i & 3) + 8 * (i >> 2) + 4 * hh; }
+
+// operand fragment of row `row` (8 consecutive fp32 at p); zeros when !ok.  p is 32-byte aligned (head dim % 8 == 0).
+template <int NP>
+__device__ __forceinline__ Frag load_kc(const float* __restrict__ p, bool ok) {
+  f32x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v = (f32x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  }
+  return split8<NP>(v);
+}
+// operand fragment gathered over the ROWS of X: slot j <- X[(row0 + slot_row(ks, j, hh)) * ld + col]; rows >= nrows give zeros
+template <int NP>
+__device__ __forceinline__ Frag load_gather(const float* __restrict__ X, long ld, int row0, int nrows, int ks, int hh, int col) {
+  f32x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = row0 + slot_row(ks, j, hh);
+    v[j] = r < nrows ? X[(long)r * ld + col] : 0.0f;
+  }
+  return split8<NP>(v);
+}
+// the eight registers 8*ks .. 8*ks+7 of an accumulator as an operand fragment
+template <int NP>
+__device__ __forceinline__ Frag acc_frag(const f32x16& a, int ks) {
+  f32x8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = a[8 * ks + j];
+  return split8<NP>(v);
+}
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+constexpr float kNegBig = -1.0e30f;
+
+struct AttnGeoK {  // pointers of one (b, h): rows are frames, ld = 3D for q / k / v, D for o / do
+  const float *q, *k, *v;
+  long ld;
+  int Tq, len;
+  long pbase;  // index of P[z][0][0] in the flat [B*H][Tq][Tq] tensor (dropout stream position)
+};
+__device__ __forceinline__ AttnGeoK attn_geo(const float* qkv, const int32_t* key_len, int H, int Tq, int D, int DH, int z) {
+  const int b = z / H, h = z % H;
+  AttnGeoK g;
+  g.q = qkv + (long)b * Tq * 3 * D + h * DH, g.k = g.q + D, g.v = g.q + 2 * D;
+  g.ld = 3L * D, g.Tq = Tq, g.len = min(key_len[b], Tq);
+  g.pbase = (long)z * Tq * Tq;
+  return g;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: ctx[q][h*DH + d] = sum_k drop(softmax_k(scale * q.k))[q][k] v[k][d];  lse[z][q] = log sum_k exp(scale * q.k)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, int NP>
+__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, float* __restrict__ ctx,
+                                                          float* __restrict__ lse, int H, int Tq, int D, float scale, Drop drop) {
+  constexpr int KSQ = DH / 16, DT = DH / 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
+  const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
+  const DropState2 ds(drop);
+  Frag qf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) qf[ks] = load_kc<NP>(g.q + (long)q * g.ld + ks * 16 + 8 * hh, q < Tq);
+  f32x16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
+  float m_run = kNegBig, l_run = 0.0f;
+  const int nkt = (g.len + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key_r = kt * 32 + r;  // the key this lane supplies as an operand row
+    f32x16 sc = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) sc = mfma3<NP>(load_kc<NP>(g.k + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), qf[ks], sc);
+    float tmax = kNegBig;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt * 32 + acc_row(i, hh);
+      sc[i] = key < g.len ? sc[i] * scale : kNegBig;
+      tmax = fmaxf(tmax, sc[i]);
+    }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax), alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    f32x16 pd;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt * 32 + acc_row(i, hh);
+      const float p = key < g.len ? __expf(sc[i] - m_new) : 0.0f;
+      psum += p;
+      pd[i] = p * ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
+    }
+    l_run = l_run * alpha + psum;
+    Frag pf[2];
+    pf[0] = acc_frag<NP>(pd, 0), pf[1] = acc_frag<NP>(pd, 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) o[dt] = mfma3<NP>(load_gather<NP>(g.v, g.ld, kt * 32, Tq, ks, hh, dt * 32 + r), pf[ks], o[dt]);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = g.len > 0 ? 1.0f / l_tot : NAN;  // no key at all: nan, as torch's masked softmax
+  if (q < Tq) {
+    float* dst = ctx + ((long)(z / H) * Tq + q) * D + (z % H) * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *(f32x4*)(dst + dt * 32 + 8 * gq + 4 * hh) = (f32x4){o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
+    if (hh == 0) lse[(long)z * Tq + q] = g.len > 0 ? m_run + __logf(l_tot) : NAN;
+  }
+}
+
+// delta[z][q] = sum_d dO[q][h*DH + d] * O[q][h*DH + d]
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict__ o, const float* __restrict__ d_o, float* __restrict__ delta, int H, int Tq,
+                                                         int D, int DH, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;  // i = z * Tq + q
+  if (i >= n) return;
+  const long z = i / Tq;
+  const int q = (int)(i - z * Tq);
+  const long off = ((z / H) * Tq + q) * D + (z % H) * DH;
+  float s = 0.0f;
+  for (int d = 0; d < DH; d += 4) {
+    const f32x4 a = *(const f32x4*)(o + off + d), b = *(const f32x4*)(d_o + off + d);
+    s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+  }
+  delta[i] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, pass over query tiles: dQ[q][d] = sum_k dS[q][k] K[k][d],  dS = scale * P * (dP_drop * mask - delta)
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, int NP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
+                                                             int H, int Tq, int D, float scale, Drop drop) {
+  constexpr int KSQ = DH / 16, DT = DH / 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
+  const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
+  const DropState2 ds(drop);
+  const float* dob = d_o + (long)(z / H) * Tq * D + (z % H) * DH;
+  Frag qf[KSQ], dof[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    qf[ks] = load_kc<NP>(g.q + (long)q * g.ld + ks * 16 + 8 * hh, q < Tq);
+    dof[ks] = load_kc<NP>(dob + (long)q * D + ks * 16 + 8 * hh, q < Tq);
+  }
+  const float lse_q = q < Tq ? lse[(long)z * Tq + q] : 0.0f, del_q = q < Tq ? delta[(long)z * Tq + q] : 0.0f;
+  f32x16 dq[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
+  const int nkt = (g.len + 31) / 32;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key_r = kt * 32 + r;
+    f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      sc = mfma3<NP>(load_kc<NP>(g.k + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), qf[ks], sc);
+      dp = mfma3<NP>(load_kc<NP>(g.v + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), dof[ks], dp);
+    }
+    f32x16 dsv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int key = kt * 32 + acc_row(i, hh);
+      const float p = (key < g.len && q < Tq) ? __expf(sc[i] * scale - lse_q) : 0.0f;
+      dsv[i] = scale * p * (dp[i] * ds.mul((uint64_t)(g.pbase + (long)q * Tq + key)) - del_q);
+    }
+    Frag dsf[2];
+    dsf[0] = acc_frag<NP>(dsv, 0), dsf[1] = acc_frag<NP>(dsv, 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) dq[dt] = mfma3<NP>(load_gather<NP>(g.k, g.ld, kt * 32, Tq, ks, hh, dt * 32 + r), dsf[ks], dq[dt]);
+  }
+  if (q < Tq) {
+    float* dst = dqkv + ((long)(z / H) * Tq + q) * 3 * D + (z % H) * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+        *(f32x4*)(dst + dt * 32 + 8 * gq + 4 * hh) = (f32x4){dq[dt][4 * gq], dq[dt][4 * gq + 1], dq[dt][4 * gq + 2], dq[dt][4 * gq + 3]};
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, pass over key tiles: dV[k][d] = sum_q P_drop[q][k] dO[q][d],  dK[k][d] = sum_q dS[q][k] Q[q][d]
+// ---------------------------------------------------------------------------------------------------------------------
+template <int DH, int NP>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
+                                                              int H, int Tq, int D, float scale, Drop drop) {
+  constexpr int KSQ = DH / 16, DT = DH / 32;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  const int z = blockIdx.y, key = blockIdx.x * 128 + w * 32 + r;  // the key this lane owns as an accumulator COLUMN
+  const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
+  const DropState2 ds(drop);
+  const float* dob = d_o + (long)(z / H) * Tq * D + (z % H) * DH;
+  Frag kf[KSQ], vf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    kf[ks] = load_kc<NP>(g.k + (long)key * g.ld + ks * 16 + 8 * hh, key < Tq);
+    vf[ks] = load_kc<NP>(g.v + (long)key * g.ld + ks * 16 + 8 * hh, key < Tq);
+  }
+  f32x16 dk[DT], dv[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) dk[dt] = zero16(), dv[dt] = zero16();
+  const bool live = key < g.len;  // masked keys keep zero gradients
+  const int nqt = (Tq + 31) / 32;
+  const bool any_live = __any(live);
+  for (int qt = 0; qt < nqt && any_live; ++qt) {
+    const int q_r = qt * 32 + r;  // the query this lane supplies as an operand row
+    f32x16 sc = zero16(), dp = zero16();
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      sc = mfma3<NP>(load_kc<NP>(g.q + (long)q_r * g.ld + ks * 16 + 8 * hh, q_r < Tq), kf[ks], sc);
+      dp = mfma3<NP>(load_kc<NP>(dob + (long)q_r * D + ks * 16 + 8 * hh, q_r < Tq), vf[ks], dp);
+    }
+    f32x16 pdv, dsv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int q = qt * 32 + acc_row(i, hh);
+      const bool ok = live && q < Tq;
+      const float lse_q = ok ? lse[(long)z * Tq + q] : 0.0f, del_q = ok ? delta[(long)z * Tq + q] : 0.0f;
+      const float p = ok ? __expf(sc[i] * scale - lse_q) : 0.0f;
+      const float m = ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
+      pdv[i] = p * m;
+      dsv[i] = scale * p * (dp[i] * m - del_q);
+    }
+    Frag pdf[2], dsf[2];
+    pdf[0] = acc_frag<NP>(pdv, 0), pdf[1] = acc_frag<NP>(pdv, 1), dsf[0] = acc_frag<NP>(dsv, 0), dsf[1] = acc_frag<NP>(dsv, 1);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        dv[dt] = mfma3<NP>(load_gather<NP>(dob, D, qt * 32, Tq, ks, hh, dt * 32 + r), pdf[ks], dv[dt]);
+        dk[dt] = mfma3<NP>(load_gather<NP>(g.q, g.ld, qt * 32, Tq, ks, hh, dt * 32 + r), dsf[ks], dk[dt]);
+      }
+  }
+  if (key < Tq) {
+    float* dst = dqkv + ((long)(z / H) * Tq + key) * 3 * D + (z % H) * DH;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        *(f32x4*)(dst + D + dt * 32 + 8 * gq + 4 * hh) = (f32x4){dk[dt][4 * gq], dk[dt][4 * gq + 1], dk[dt][4 * gq + 2], dk[dt][4 * gq + 3]};
+        *(f32x4*)(dst + 2 * D + dt * 32 + 8 * gq + 4 * hh) = (f32x4){dv[dt][4 * gq], dv[dt][4 * gq + 1], dv[dt][4 * gq + 2], dv[dt][4 * gq + 3]};
+      }
+  }
+}
+
+bool attn_fused_supported(int D, int H) {
+  const int dh = H > 0 ? D / H : 0;
+  return H > 0 && D % H == 0 && (dh == 32 || dh == 64) && D % 8 == 0;
+}
+
+hipError_t launch_attn_fwd_fused(const float* qkv, const int32_t* key_len, float* ctx, float* lse, int B, int H, int Tq, int D, int np, Drop d,
+                                 hipStream_t st) {
+  if (!attn_fused_supported(D, H)) return hipErrorInvalidValue;
+  const int dh = D / H;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const dim3 grid((Tq + 127) / 128, B * H);
+#define EECT_AF(DHv, NPv) hipLaunchKernelGGL((attn_fwd_kernel<DHv, NPv>), grid, dim3(256), 0, st, qkv, key_len, ctx, lse, H, Tq, D, scale, d)
+  if (dh == 32) { if (np == 1) EECT_AF(32, 1); else EECT_AF(32, 3); }
+  else { if (np == 1) EECT_AF(64, 1); else EECT_AF(64, 3); }
+#undef EECT_AF
+  return hipGetLastError();
+}
+
+hipError_t launch_attn_bwd_fused(const float* qkv, const int32_t* key_len, const float* ctx, const float* d_ctx, const float* lse, float* delta,
+                                 float* dqkv, int B, int H, int Tq, int D, int np, Drop d, hipStream_t st) {
+  if (!attn_fused_supported(D, H)) return hipErrorInvalidValue;
+  const int dh = D / H;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const long n = (long)B * H * Tq;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx, d_ctx, delta, H, Tq, D, dh, n);
+  const dim3 grid((Tq + 127) / 128, B * H);
+#define EECT_AB(K, DHv, NPv) hipLaunchKernelGGL((K<DHv, NPv>), grid, dim3(256), 0, st, qkv, key_len, d_ctx, lse, (const float*)delta, dqkv, H, Tq, D, scale, d)
+  if (dh == 32) {
+    if (np == 1) { EECT_AB(attn_bwd_dq_kernel, 32, 1); EECT_AB(attn_bwd_dkv_kernel, 32, 1); }
+    else { EECT_AB(attn_bwd_dq_kernel, 32, 3); EECT_AB(attn_bwd_dkv_kernel, 32, 3); }
+  } else {
+    if (np == 1) { EECT_AB(attn_bwd_dq_kernel, 64, 1); EECT_AB(attn_bwd_dkv_kernel, 64, 1); }
+    else { EECT_AB(attn_bwd_dq_kernel, 64, 3); EECT_AB(attn_bwd_dkv_kernel, 64, 3); }
+  }
+#undef EECT_AB
+  return hipGetLastError();
+}
+
+}  // namespace eect

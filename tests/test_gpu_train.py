@@ -108,11 +108,13 @@ def test_training_step_matches_oracle_autograd(cfg, B, T, lens):
     compare_grads(grads_of(gpu), grads_of(ref), 0.15, "bf16")
 
 
-def test_dropout_masks_are_consistent_between_forward_and_backward():
+@pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2)], ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention"])
+def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     """drop_prob > 0: streams cannot match torch's, so the check is internal -- the same seed reproduces the step, another
     seed changes it, and the analytic gradient matches a central finite difference of the SAME masked network along a
-    random direction in parameter space."""
-    kw = base_kwargs(**SMALL)
+    random direction in parameter space.  Both attention paths: batched GEMMs + softmax kernels (head dim 16) and the fused
+    kernels that regenerate the attention-probability mask in three places (head dim 32)."""
+    kw = base_kwargs(**cfg)
     _, gpu = make_train_pair(kw, seed=5, drop=0.1)
     mel, lens = synth.synth_mel(2, 80, 99, seed=5).cuda(), torch.tensor([99, 70])
     tgt, tl = synth.synth_targets(2, 6, 32, seed=5)
