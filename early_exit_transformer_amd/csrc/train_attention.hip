@@ -124,7 +124,7 @@ __device__ __forceinline__ AttnGeoK attn_geo(const float* qkv, const int32_t* ke
 // forward: ctx[q][h*DH + d] = sum_k drop(softmax_k(scale * q.k))[q][k] v[k][d];  lse[z][q] = log sum_k exp(scale * q.k)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, int NP>
-__global__ __launch_bounds__(256, 1) void attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, float* __restrict__ ctx,
+__global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, float* __restrict__ ctx,
                                                           float* __restrict__ lse, int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float* __restrict
 // backward, pass over query tiles: dQ[q][d] = sum_k dS[q][k] K[k][d],  dS = scale * P * (dP_drop * mask - delta)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, int NP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
+__global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
                                                              const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                              int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
@@ -292,12 +292,31 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
       sc = mfma3<NP>(load_kc<NP>(g.q + (long)q_r * g.ld + ks * 16 + 8 * hh, q_r < Tq), kf[ks], sc);
       dp = mfma3<NP>(load_kc<NP>(dob + (long)q_r * D + ks * 16 + 8 * hh, q_r < Tq), vf[ks], dp);
     }
+    // lse / delta of the 16 query rows of this lane: rows come in runs of four (acc_row), one 16-byte load per run when the
+    // tile is inside the utterance and T' % 4 == 0
+    float lse_r[16], del_r[16];
+    const bool vec_rows = (Tq & 3) == 0 && qt * 32 + 32 <= Tq;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const long o4 = (long)z * Tq + qt * 32 + 8 * gq + 4 * hh;
+      if (vec_rows) {
+        const f32x4 a = *(const f32x4*)(lse + o4), b = *(const f32x4*)(delta + o4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lse_r[4 * gq + e] = a[e], del_r[4 * gq + e] = b[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool in = qt * 32 + 8 * gq + 4 * hh + e < Tq;
+          lse_r[4 * gq + e] = in ? lse[o4 + e] : 0.0f, del_r[4 * gq + e] = in ? delta[o4 + e] : 0.0f;
+        }
+      }
+    }
     f32x16 pdv, dsv;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int q = qt * 32 + acc_row(i, hh);
       const bool ok = live && q < Tq;
-      const float lse_q = ok ? lse[(long)z * Tq + q] : 0.0f, del_q = ok ? delta[(long)z * Tq + q] : 0.0f;
+      const float lse_q = lse_r[i], del_q = del_r[i];
       const float p = ok ? __expf(sc[i] * scale - lse_q) : 0.0f;
       const float m = ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
       pdv[i] = p * m;
