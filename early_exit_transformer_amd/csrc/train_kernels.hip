@@ -313,22 +313,25 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   float* __restrict__ C2 = g.C2;
   float* slab = (float*)smem;
   const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
+  // what a slab's elements need from memory -- old C (accumulate) or aux (EPI_DSILU), never both -- is requested one slab
+  // ahead: the loads of slab s + 1 are in flight while slab s goes through LDS and out
+  constexpr int NPS = 32 * (BN / 4) / 256;
+  f32x4 pre[BM / 32][NPS];
+  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU);
+  const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
+  auto request = [&](auto sl_tag) __attribute__((always_inline)) {
+    constexpr int sl = decltype(sl_tag)::value;
+#pragma unroll
+    for (int ps = 0; ps < NPS; ++ps) {
+      const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const int m = m0 + sl * 32 + row, n = n0 + c4;
+      pre[sl][ps] = (want_pre && m < g.M && n < g.N) ? *(const f32x4*)(pre_src + (long)m * g.c_m + n) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    }
+  };
+  request(IntTag<0>{});
   static_for<0, BM / 32>([&](auto sl_tag) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_tag)::value;
-    constexpr int NPS = 32 * (BN / 4) / 256;
-    // what the slab's elements need from memory (old C, aux) is requested first: in flight across the LDS hand-over
-    f32x4 oldv[NPS], auxv[NPS];
-    if (cvec) {
-#pragma unroll
-      for (int ps = 0; ps < NPS; ++ps) {
-        const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
-        const int m = m0 + sl * 32 + row, n = n0 + c4;
-        const bool ok = m < g.M && n < g.N;
-        const long ci = (long)m * g.c_m + n;
-        oldv[ps] = (g.accumulate && ok) ? *(const f32x4*)(C + ci) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-        auxv[ps] = (g.epi == EPI_DSILU && ok) ? *(const f32x4*)(aux + ci) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-      }
-    }
+    if constexpr (sl + 1 < BM / 32) request(IntTag<sl + 1>{});
     if (wm == sl / TM) {
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt)
@@ -349,11 +352,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
         for (int j = 0; j < 4; ++j) v[j] = g.alpha * a4[j] + ((g.bias && j < nvalid) ? g.bias[n + j] : 0.0f);
         if (cvec) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += oldv[ps][j];
+          for (int j = 0; j < 4; ++j) v[j] += g.accumulate ? pre[sl][ps][j] : 0.0f;
           if (g.epi == EPI_DSILU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float x = auxv[ps][j], sg = 1.0f / (1.0f + __expf(-x));
+              const float x = pre[sl][ps][j], sg = 1.0f / (1.0f + __expf(-x));
               v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
             }
           }
