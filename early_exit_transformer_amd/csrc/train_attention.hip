@@ -10,6 +10,10 @@
 // k-step ks; the partner operand is gathered from memory with the same slot -> row map.
 #include "eec_train.h"
 
+namespace eec {
+hipError_t ensure_max_lds(const void* kernel, int bytes);  // pack.hip: per-device MaxDynamicSharedMemorySize attribute
+}
+
 namespace eect {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -121,13 +125,93 @@ __device__ __forceinline__ AttnGeoK attn_geo(const float* qkv, const int32_t* ke
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Tiles shared by the four waves of a workgroup: a 32-row x DH block of an fp32 matrix is loaded and split ONCE per
+// workgroup into LDS, as bf16 hi / lo planes in the row layout ([32][DH + 8]: ds_read_b128 = the 8 consecutive-d operand
+// of a row) and / or the slot layout ([DH][40]: ds_read_b128 = the 8 k-slots of column d, rows stored at slot_pos(row)).
+// Two buffers: the global loads of tile t + 1 are issued before tile t is consumed and written to LDS after it.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int DH, int NP, bool ROWL, bool SLOTL>
+struct TileLds {
+  static constexpr int kLdR = DH + 8, kLdT = 40, kPl = NP == 3 ? 2 : 1;  // planes per layout
+  static constexpr int kRow = 32 * kLdR, kSlot = DH * kLdT;
+  static constexpr int kRowLo = kRow, kSlotHi = ROWL ? kPl * kRow : 0, kSlotLo = kSlotHi + kSlot;
+  static constexpr int kElems = (ROWL ? kPl * kRow : 0) + (SLOTL ? kPl * kSlot : 0);
+};
+__device__ __forceinline__ int slot_pos(int row) {  // inverse of slot_row: where tile row `row` sits among the 32 slots
+  const int x = row & 15;
+  return (row & 16) + ((x >> 2) & 1) * 8 + ((x >> 3) << 2) + (x & 3);
+}
+template <int DH>
+struct StageRegs {
+  f32x4 v[DH / 32];
+};
+template <int DH>
+__device__ __forceinline__ void stage_issue(StageRegs<DH>& sr, const float* __restrict__ X, long ld, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int it = 0; it < DH / 32; ++it) {
+    const int idx = it * 256 + tid, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+    const int rr = row0 + row;
+    sr.v[it] = rr < nrows ? *(const f32x4*)(X + (long)rr * ld + c4) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+  }
+}
+template <int DH, int NP, bool ROWL, bool SLOTL>
+__device__ __forceinline__ void stage_commit(const StageRegs<DH>& sr, bf16* __restrict__ tile, int tid) {
+  using T = TileLds<DH, NP, ROWL, SLOTL>;
+#pragma unroll
+  for (int it = 0; it < DH / 32; ++it) {
+    const int idx = it * 256 + tid, row = idx / (DH / 4), c4 = (idx % (DH / 4)) * 4;
+    const bf16x4 h = __builtin_convertvector(sr.v[it], bf16x4);
+    bf16x4 l = h;
+    if (NP == 3) l = __builtin_convertvector(sr.v[it] - __builtin_convertvector(h, f32x4), bf16x4);
+    if (ROWL) {
+      *(bf16x4*)(tile + row * T::kLdR + c4) = h;
+      if (NP == 3) *(bf16x4*)(tile + T::kRowLo + row * T::kLdR + c4) = l;
+    }
+    if (SLOTL) {
+      const int pos = slot_pos(row);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        tile[T::kSlotHi + (c4 + e) * T::kLdT + pos] = h[e];
+        if (NP == 3) tile[T::kSlotLo + (c4 + e) * T::kLdT + pos] = l[e];
+      }
+    }
+  }
+}
+template <int DH, int NP, bool ROWL, bool SLOTL>
+__device__ __forceinline__ Frag row_frag(const bf16* __restrict__ tile, int row, int ks, int hh) {
+  using T = TileLds<DH, NP, ROWL, SLOTL>;
+  Frag f;
+  f.hi = *(const bf16x8*)(tile + row * T::kLdR + ks * 16 + 8 * hh);
+  f.lo = NP == 3 ? *(const bf16x8*)(tile + T::kRowLo + row * T::kLdR + ks * 16 + 8 * hh) : f.hi;
+  return f;
+}
+template <int DH, int NP, bool ROWL, bool SLOTL>
+__device__ __forceinline__ Frag slot_frag(const bf16* __restrict__ tile, int col, int ks, int hh) {
+  using T = TileLds<DH, NP, ROWL, SLOTL>;
+  Frag f;
+  f.hi = *(const bf16x8*)(tile + T::kSlotHi + col * T::kLdT + ks * 16 + 8 * hh);
+  f.lo = NP == 3 ? *(const bf16x8*)(tile + T::kSlotLo + col * T::kLdT + ks * 16 + 8 * hh) : f.hi;
+  return f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // forward: ctx[q][h*DH + d] = sum_k drop(softmax_k(scale * q.k))[q][k] v[k][d];  lse[z][q] = log sum_k exp(scale * q.k)
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, int NP>
 __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, float* __restrict__ ctx,
                                                           float* __restrict__ lse, int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  using TK = TileLds<DH, NP, true, false>;   // K: row layout
+  using TV = TileLds<DH, NP, false, true>;   // V: slot layout
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* const lds0 = (bf16*)smem;
+  bf16* kt_lds[2];
+  bf16* vt_lds[2];
+  kt_lds[0] = lds0, kt_lds[1] = lds0 + TK::kElems, vt_lds[0] = lds0 + 2 * TK::kElems, vt_lds[1] = lds0 + 2 * TK::kElems + TV::kElems;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
@@ -138,12 +222,25 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) o[dt] = zero16();
   float m_run = kNegBig, l_run = 0.0f;
-  const int nkt = (g.len + 31) / 32;
+  const int nkt = (g.len + 31) / 32;  // uniform over the workgroup
+  StageRegs<DH> sk, sv;
+  if (nkt > 0) {
+    stage_issue<DH>(sk, g.k, g.ld, 0, Tq, tid);
+    stage_issue<DH>(sv, g.v, g.ld, 0, Tq, tid);
+    stage_commit<DH, NP, true, false>(sk, kt_lds[0], tid);
+    stage_commit<DH, NP, false, true>(sv, vt_lds[0], tid);
+  }
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const int key_r = kt * 32 + r;  // the key this lane supplies as an operand row
+    const bf16* kt_t = kt_lds[kt & 1];
+    const bf16* vt_t = vt_lds[kt & 1];
+    if (kt + 1 < nkt) {
+      stage_issue<DH>(sk, g.k, g.ld, (kt + 1) * 32, Tq, tid);
+      stage_issue<DH>(sv, g.v, g.ld, (kt + 1) * 32, Tq, tid);
+    }
     f32x16 sc = zero16();
 #pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) sc = mfma3<NP>(load_kc<NP>(g.k + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), qf[ks], sc);
+    for (int ks = 0; ks < KSQ; ++ks) sc = mfma3<NP>(row_frag<DH, NP, true, false>(kt_t, r, ks, hh), qf[ks], sc);
     float tmax = kNegBig;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -171,8 +268,13 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) o[dt] = mfma3<NP>(load_gather<NP>(g.v, g.ld, kt * 32, Tq, ks, hh, dt * 32 + r), pf[ks], o[dt]);
+      for (int ks = 0; ks < 2; ++ks) o[dt] = mfma3<NP>(slot_frag<DH, NP, false, true>(vt_t, dt * 32 + r, ks, hh), pf[ks], o[dt]);
     }
+    if (kt + 1 < nkt) {
+      stage_commit<DH, NP, true, false>(sk, kt_lds[(kt + 1) & 1], tid);
+      stage_commit<DH, NP, false, true>(sv, vt_lds[(kt + 1) & 1], tid);
+    }
+    __syncthreads();
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = g.len > 0 ? 1.0f / l_tot : NAN;  // no key at all: nan, as torch's masked softmax
@@ -211,7 +313,14 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
                                                              const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                              int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  using TK = TileLds<DH, NP, true, true>;    // K: row layout (scores) and slot layout (dQ)
+  using TV = TileLds<DH, NP, true, false>;   // V: row layout (dP)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* const lds0 = (bf16*)smem;
+  bf16* kt_lds[2];
+  bf16* vt_lds[2];
+  kt_lds[0] = lds0, kt_lds[1] = lds0 + TK::kElems, vt_lds[0] = lds0 + 2 * TK::kElems, vt_lds[1] = lds0 + 2 * TK::kElems + TV::kElems;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
@@ -227,13 +336,26 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
   const int nkt = (g.len + 31) / 32;
+  StageRegs<DH> sk, sv;
+  if (nkt > 0) {
+    stage_issue<DH>(sk, g.k, g.ld, 0, Tq, tid);
+    stage_issue<DH>(sv, g.v, g.ld, 0, Tq, tid);
+    stage_commit<DH, NP, true, true>(sk, kt_lds[0], tid);
+    stage_commit<DH, NP, true, false>(sv, vt_lds[0], tid);
+  }
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const int key_r = kt * 32 + r;
+    const bf16* kt_t = kt_lds[kt & 1];
+    const bf16* vt_t = vt_lds[kt & 1];
+    if (kt + 1 < nkt) {
+      stage_issue<DH>(sk, g.k, g.ld, (kt + 1) * 32, Tq, tid);
+      stage_issue<DH>(sv, g.v, g.ld, (kt + 1) * 32, Tq, tid);
+    }
     f32x16 sc = zero16(), dp = zero16();
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
-      sc = mfma3<NP>(load_kc<NP>(g.k + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), qf[ks], sc);
-      dp = mfma3<NP>(load_kc<NP>(g.v + (long)key_r * g.ld + ks * 16 + 8 * hh, key_r < Tq), dof[ks], dp);
+      sc = mfma3<NP>(row_frag<DH, NP, true, true>(kt_t, r, ks, hh), qf[ks], sc);
+      dp = mfma3<NP>(row_frag<DH, NP, true, false>(vt_t, r, ks, hh), dof[ks], dp);
     }
     f32x16 dsv;
 #pragma unroll
@@ -247,7 +369,12 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) dq[dt] = mfma3<NP>(load_gather<NP>(g.k, g.ld, kt * 32, Tq, ks, hh, dt * 32 + r), dsf[ks], dq[dt]);
+      for (int ks = 0; ks < 2; ++ks) dq[dt] = mfma3<NP>(slot_frag<DH, NP, true, true>(kt_t, dt * 32 + r, ks, hh), dsf[ks], dq[dt]);
+    if (kt + 1 < nkt) {
+      stage_commit<DH, NP, true, true>(sk, kt_lds[(kt + 1) & 1], tid);
+      stage_commit<DH, NP, true, false>(sv, vt_lds[(kt + 1) & 1], tid);
+    }
+    __syncthreads();
   }
   if (q < Tq) {
     float* dst = dqkv + ((long)(z / H) * Tq + q) * 3 * D + (z % H) * DH;
@@ -267,7 +394,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
                                                               const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                               int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 31, hh = lane >> 5;
+  using T = TileLds<DH, NP, true, true>;  // Q and dO: both layouts
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16* const lds0 = (bf16*)smem;
+  bf16* qt_lds[2];
+  bf16* dot_lds[2];
+  qt_lds[0] = lds0, qt_lds[1] = lds0 + T::kElems, dot_lds[0] = lds0 + 2 * T::kElems, dot_lds[1] = lds0 + 3 * T::kElems;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 31, hh = lane >> 5;
   const int z = blockIdx.y, key = blockIdx.x * 128 + w * 32 + r;  // the key this lane owns as an accumulator COLUMN
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
@@ -282,15 +415,27 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dk[dt] = zero16(), dv[dt] = zero16();
   const bool live = key < g.len;  // masked keys keep zero gradients
-  const int nqt = (Tq + 31) / 32;
-  const bool any_live = __any(live);
-  for (int qt = 0; qt < nqt && any_live; ++qt) {
-    const int q_r = qt * 32 + r;  // the query this lane supplies as an operand row
+  const int nqt = (int)blockIdx.x * 128 < g.len ? (Tq + 31) / 32 : 0;  // uniform over the workgroup: a fully masked key block skips the walk
+  StageRegs<DH> sq, sd;
+  if (nqt > 0) {
+    stage_issue<DH>(sq, g.q, g.ld, 0, Tq, tid);
+    stage_issue<DH>(sd, dob, D, 0, Tq, tid);
+    stage_commit<DH, NP, true, true>(sq, qt_lds[0], tid);
+    stage_commit<DH, NP, true, true>(sd, dot_lds[0], tid);
+  }
+  __syncthreads();
+  for (int qt = 0; qt < nqt; ++qt) {
+    const bf16* q_t = qt_lds[qt & 1];
+    const bf16* do_t = dot_lds[qt & 1];
+    if (qt + 1 < nqt) {
+      stage_issue<DH>(sq, g.q, g.ld, (qt + 1) * 32, Tq, tid);
+      stage_issue<DH>(sd, dob, D, (qt + 1) * 32, Tq, tid);
+    }
     f32x16 sc = zero16(), dp = zero16();
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
-      sc = mfma3<NP>(load_kc<NP>(g.q + (long)q_r * g.ld + ks * 16 + 8 * hh, q_r < Tq), kf[ks], sc);
-      dp = mfma3<NP>(load_kc<NP>(dob + (long)q_r * D + ks * 16 + 8 * hh, q_r < Tq), vf[ks], dp);
+      sc = mfma3<NP>(row_frag<DH, NP, true, true>(q_t, r, ks, hh), kf[ks], sc);
+      dp = mfma3<NP>(row_frag<DH, NP, true, true>(do_t, r, ks, hh), vf[ks], dp);
     }
     // lse / delta of the 16 query rows of this lane: rows come in runs of four (acc_row), one 16-byte load per run when the
     // tile is inside the utterance and T' % 4 == 0
@@ -316,11 +461,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
     for (int i = 0; i < 16; ++i) {
       const int q = qt * 32 + acc_row(i, hh);
       const bool ok = live && q < Tq;
-      const float lse_q = lse_r[i], del_q = del_r[i];
-      const float p = ok ? __expf(sc[i] * scale - lse_q) : 0.0f;
+      const float p = ok ? __expf(sc[i] * scale - lse_r[i]) : 0.0f;
       const float m = ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
       pdv[i] = p * m;
-      dsv[i] = scale * p * (dp[i] * m - del_q);
+      dsv[i] = scale * p * (dp[i] * m - del_r[i]);
     }
     Frag pdf[2], dsf[2];
     pdf[0] = acc_frag<NP>(pdv, 0), pdf[1] = acc_frag<NP>(pdv, 1), dsf[0] = acc_frag<NP>(dsv, 0), dsf[1] = acc_frag<NP>(dsv, 1);
@@ -328,9 +472,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __res
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        dv[dt] = mfma3<NP>(load_gather<NP>(dob, D, qt * 32, Tq, ks, hh, dt * 32 + r), pdf[ks], dv[dt]);
-        dk[dt] = mfma3<NP>(load_gather<NP>(g.q, g.ld, qt * 32, Tq, ks, hh, dt * 32 + r), dsf[ks], dk[dt]);
+        dv[dt] = mfma3<NP>(slot_frag<DH, NP, true, true>(do_t, dt * 32 + r, ks, hh), pdf[ks], dv[dt]);
+        dk[dt] = mfma3<NP>(slot_frag<DH, NP, true, true>(q_t, dt * 32 + r, ks, hh), dsf[ks], dk[dt]);
       }
+    if (qt + 1 < nqt) {
+      stage_commit<DH, NP, true, true>(sq, qt_lds[(qt + 1) & 1], tid);
+      stage_commit<DH, NP, true, true>(sd, dot_lds[(qt + 1) & 1], tid);
+    }
+    __syncthreads();
   }
   if (key < Tq) {
     float* dst = dqkv + ((long)(z / H) * Tq + key) * 3 * D + (z % H) * DH;
@@ -349,17 +498,29 @@ bool attn_fused_supported(int D, int H) {
   return H > 0 && D % H == 0 && (dh == 32 || dh == 64) && D % 8 == 0;
 }
 
+template <typename K, typename... Args>
+static hipError_t launch_with_lds(K kernel, dim3 grid, size_t lds, hipStream_t st, Args... args) {
+  if (hipError_t e = eec::ensure_max_lds((const void*)kernel, (int)lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, args...);
+  return hipGetLastError();
+}
+template <int DH, int NP>
+static size_t fwd_lds() { return 2 * (TileLds<DH, NP, true, false>::kElems + TileLds<DH, NP, false, true>::kElems) * sizeof(bf16); }
+template <int DH, int NP>
+static size_t dq_lds() { return 2 * (TileLds<DH, NP, true, true>::kElems + TileLds<DH, NP, true, false>::kElems) * sizeof(bf16); }
+template <int DH, int NP>
+static size_t dkv_lds() { return 4 * TileLds<DH, NP, true, true>::kElems * sizeof(bf16); }
+
 hipError_t launch_attn_fwd_fused(const float* qkv, const int32_t* key_len, float* ctx, float* lse, int B, int H, int Tq, int D, int np, Drop d,
                                  hipStream_t st) {
   if (!attn_fused_supported(D, H)) return hipErrorInvalidValue;
   const int dh = D / H;
   const float scale = 1.0f / sqrtf((float)dh);
   const dim3 grid((Tq + 127) / 128, B * H);
-#define EECT_AF(DHv, NPv) hipLaunchKernelGGL((attn_fwd_kernel<DHv, NPv>), grid, dim3(256), 0, st, qkv, key_len, ctx, lse, H, Tq, D, scale, d)
+#define EECT_AF(DHv, NPv) return launch_with_lds(attn_fwd_kernel<DHv, NPv>, grid, fwd_lds<DHv, NPv>(), st, qkv, key_len, ctx, lse, H, Tq, D, scale, d)
   if (dh == 32) { if (np == 1) EECT_AF(32, 1); else EECT_AF(32, 3); }
   else { if (np == 1) EECT_AF(64, 1); else EECT_AF(64, 3); }
 #undef EECT_AF
-  return hipGetLastError();
 }
 
 hipError_t launch_attn_bwd_fused(const float* qkv, const int32_t* key_len, const float* ctx, const float* d_ctx, const float* lse, float* delta,
@@ -370,16 +531,19 @@ hipError_t launch_attn_bwd_fused(const float* qkv, const int32_t* key_len, const
   const long n = (long)B * H * Tq;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ctx, d_ctx, delta, H, Tq, D, dh, n);
   const dim3 grid((Tq + 127) / 128, B * H);
-#define EECT_AB(K, DHv, NPv) hipLaunchKernelGGL((K<DHv, NPv>), grid, dim3(256), 0, st, qkv, key_len, d_ctx, lse, (const float*)delta, dqkv, H, Tq, D, scale, d)
-  if (dh == 32) {
-    if (np == 1) { EECT_AB(attn_bwd_dq_kernel, 32, 1); EECT_AB(attn_bwd_dkv_kernel, 32, 1); }
-    else { EECT_AB(attn_bwd_dq_kernel, 32, 3); EECT_AB(attn_bwd_dkv_kernel, 32, 3); }
-  } else {
-    if (np == 1) { EECT_AB(attn_bwd_dq_kernel, 64, 1); EECT_AB(attn_bwd_dkv_kernel, 64, 1); }
-    else { EECT_AB(attn_bwd_dq_kernel, 64, 3); EECT_AB(attn_bwd_dkv_kernel, 64, 3); }
-  }
+  const float* cdelta = delta;
+#define EECT_AB(DHv, NPv)                                                                                                                     \
+  do {                                                                                                                                        \
+    if (hipError_t e = launch_with_lds(attn_bwd_dq_kernel<DHv, NPv>, grid, dq_lds<DHv, NPv>(), st, qkv, key_len, d_ctx, lse, cdelta, dqkv, H, \
+                                       Tq, D, scale, d);                                                                                      \
+        e != hipSuccess)                                                                                                                      \
+      return e;                                                                                                                               \
+    return launch_with_lds(attn_bwd_dkv_kernel<DHv, NPv>, grid, dkv_lds<DHv, NPv>(), st, qkv, key_len, d_ctx, lse, cdelta, dqkv, H, Tq, D,    \
+                           scale, d);                                                                                                         \
+  } while (0)
+  if (dh == 32) { if (np == 1) EECT_AB(32, 1); else EECT_AB(32, 3); }
+  else { if (np == 1) EECT_AB(64, 1); else EECT_AB(64, 3); }
 #undef EECT_AB
-  return hipGetLastError();
 }
 
 }  // namespace eect
