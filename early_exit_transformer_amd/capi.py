@@ -152,9 +152,9 @@ def load() -> C.CDLL:
     lib.eec_trainer_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_trainer_workspace_bytes.restype = C.c_size_t
     lib.eec_train_forward.argtypes = [C.c_void_p, C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
-                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                      C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_train_backward.argtypes = [C.c_void_p, C.POINTER(EecParams), C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_void_p,
-                                       C.c_size_t, C.c_void_p]
+                                       C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
     lib.eec_decoder_last_error.restype = C.c_char_p

@@ -248,7 +248,7 @@ float* conv_fwd(Run& r, ConvTape& t, float* x, const eec_layer_params& L, float*
   return y;
 }
 
-void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengths, float* out, float* bn_mv) {
+void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengths, float* out, float* bn_mv, float* taps) {
   eec_trainer* tr = r.tr;
   const eec_config& c = tr->cfg;
   const int B = tr->B, T = tr->T, T1 = tr->T1, Tq = tr->Tq, M = tr->M, D = c.d_model, C = c.n_mels, V = c.vocab;
@@ -281,6 +281,7 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
       RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
       x = t.out;
     }
+    if (taps) RUN(hipMemcpyAsync(taps + (size_t)e * M * D, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     r.scr.reset();
     float* logits = r.scr.f((size_t)M * V);
     linear_fwd(r, x, P->head_w[e], P->head_b[e], logits, M, V, D);
@@ -382,7 +383,7 @@ void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, e
   ln_bwd(r, dv, t.x, L.conv_ln_w, t.mean, t.rstd, dx, true, (float*)G.conv_ln_w, (float*)G.conv_ln_b, M, D);
 }
 
-void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out) {
+void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out, const float* grad_taps) {
   eec_trainer* tr = r.tr;
   const eec_config& c = tr->cfg;
   const int B = tr->B, T1 = tr->T1, Tq = tr->Tq, M = tr->M, D = c.d_model, C = c.n_mels, V = c.vocab;
@@ -395,6 +396,7 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
     RUN(eec::launch_logsoftmax_backward(out + (size_t)e * M * V, grad_out + (size_t)e * M * V, M, V, dlogits, r.st));
     linear_bwd_weight(r, dlogits, tap, (float*)Gp->head_w[e], (float*)Gp->head_b[e], M, V, D);
     linear_bwd_data(r, dlogits, P->head_w[e], dx, M, V, D, e != c.n_exits - 1);
+    if (grad_taps) RUN(launch_axpy(dx, grad_taps + (size_t)e * M * D, 1.0f, (long)M * D, r.st));  // what the caller did with the tap itself
     for (int l = c.layers_per_exit - 1; l >= 0; --l) {
       const int li = e * c.layers_per_exit + l;
       const eec_layer_params& L = P->layers[li];
@@ -480,15 +482,16 @@ size_t eec_trainer_workspace_bytes(const eec_trainer* tr_in, int B, int T) {
   std::vector<const float*> heads(tmp.cfg.n_exits, nullptr);
   eec_params P{};
   P.layers = layers.data(), P.head_w = heads.data(), P.head_b = heads.data();
-  forward(r, &P, nullptr, nullptr, nullptr, nullptr);
+  forward(r, &P, nullptr, nullptr, nullptr, nullptr, nullptr);
   const size_t fwd_scr = r.scr.peak;
   r.scr = Bump{};
-  backward(r, &P, &P, nullptr, nullptr);
+  backward(r, &P, &P, nullptr, nullptr, nullptr);
   return (r.tape.peak + 256) + std::max(fwd_scr, r.scr.peak) + 4096;
 }
 
 int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* mel, const int64_t* lengths, int B, int T, int passes,
-                      float drop_prob, uint64_t seed, float* out, float* bn_batch_stats, void* workspace, size_t workspace_bytes, void* stream) {
+                      float drop_prob, uint64_t seed, float* out, float* taps, float* bn_batch_stats, void* workspace, size_t workspace_bytes,
+                      void* stream) {
   if (!tr || !params || !mel || !lengths || !out || !workspace) return tfail(EEC_ERR_BAD_ARG, "null argument");
   if (passes != 1 && passes != 3) return tfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
   if (!(drop_prob >= 0.0f && drop_prob < 1.0f)) return tfail(EEC_ERR_BAD_ARG, "drop_prob in [0, 1)");
@@ -505,7 +508,7 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
   {
     eec_trainer tmp = *tr;
     Run d{&tmp, true, nullptr};
-    forward(d, params, mel, lengths, out, bn_batch_stats);
+    forward(d, params, mel, lengths, out, bn_batch_stats, taps);
     tr->tape_bytes = (d.tape.peak + 255) / 256 * 256;
   }
   r.scr.base = (char*)workspace + tr->tape_bytes;
@@ -515,10 +518,10 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
   {  // the scratch need of this forward, before any launch
     eec_trainer tmp = *tr;
     Run d{&tmp, true, nullptr};
-    forward(d, params, mel, lengths, out, bn_batch_stats);
+    forward(d, params, mel, lengths, out, bn_batch_stats, taps);
     if (d.scr.peak > r.scr.cap) return tfail(EEC_ERR_WORKSPACE, "workspace too small for the forward scratch");
   }
-  forward(r, params, mel, lengths, out, bn_batch_stats);
+  forward(r, params, mel, lengths, out, bn_batch_stats, taps);
   if (r.tape.overflow || r.scr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   tr->recorded = true;
@@ -526,7 +529,7 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
 }
 
 int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
-                       void* workspace, size_t workspace_bytes, void* stream) {
+                       const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream) {
   if (!tr || !params || !grads || !out || !grad_out || !workspace) return tfail(EEC_ERR_BAD_ARG, "null argument");
   if (!tr->recorded) return tfail(EEC_ERR_BAD_ARG, "no recorded forward (eec_train_forward first, same workspace)");
   int dev = -1;
@@ -542,13 +545,13 @@ int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_para
   {  // the scratch need of this backward, before any launch
     eec_trainer tmp = *tr;
     Run d{&tmp, true, nullptr};
-    backward(d, params, grads, out, grad_out);
+    backward(d, params, grads, out, grad_out, grad_taps);
     if (d.scr.peak > r.scr.cap || d.tape.peak > r.tape.cap)
       return tfail(EEC_ERR_WORKSPACE, "workspace too small for the backward scratch: need " + std::to_string(d.scr.peak) + " + " +
                                           std::to_string(d.tape.peak) + ", have " + std::to_string(r.scr.cap) + " + " + std::to_string(r.tape.cap) +
                                           " (workspace " + std::to_string(workspace_bytes) + ", tape " + std::to_string(tr->tape_bytes) + ")");
   }
-  backward(r, params, grads, out, grad_out);
+  backward(r, params, grads, out, grad_out, grad_taps);
   if (r.tape.overflow || r.scr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   return 0;

@@ -65,6 +65,7 @@ class _HipEncoderMixin:
     _head_attr = "linears"
     _pe_attr = "positional_encoder"
     precision = "f16f8"  # fastest operand mode that meets the 1e-3 log-prob tolerance
+    train_passes = 3     # training GEMMs: 3 = bf16 hi/lo split, three MFMA products (~fp32 results); 1 = plain bf16 operands
 
     def _hip_init(self, d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len):
         self._cfg = capi.EecConfig(d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len,
@@ -249,8 +250,6 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         self._hip_init(d_model, n_head, d_feed_forward, depthwise_kernel_size, n_enc_exits, n_enc_layers,
                        features_length, dec_voc_size, max_len)
 
-    train_passes = 3  # training GEMMs: 3 = bf16 hi/lo split, three MFMA products (~fp32 results); 1 = plain bf16 operands
-
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
         if self.training and type(self) is Early_conformer:
             # train-mode semantics (batch-statistics BatchNorm, dropout) whenever the module is in train mode -- with or
@@ -262,16 +261,19 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
             return self._forward_heads_trainable(src, lengths)
         return self._run_encoder(src, lengths)[0]
 
-    def _forward_train(self, src: Tensor, lengths: Tensor) -> Tensor:
-        """The training step's forward (train.py:54) on the HIP training kernels; autograd reaches every parameter."""
+    def _forward_train(self, src: Tensor, lengths: Tensor, want_taps: bool = False):
+        """The training step's forward (train.py:54) on the HIP training kernels; autograd reaches every parameter of the
+        path (stem, Conformer groups, exit heads).  ``want_taps``: also return the group outputs [E, B, T', D] as a second
+        differentiable result (what full_conformer hands to its attention decoders)."""
         if not src.is_cuda:
             raise RuntimeError("the MI355X training step runs on a HIP device only (there is no CPU fallback)")
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
             raise ValueError(f"src must be [B, {self._cfg.n_mels}, T], got {tuple(src.shape)}")
-        named = [(n, p) for n, p in self.named_parameters()]
+        mine = ("conv_subsample.", "conformer.", self._head_attr + ".")
+        named = [(n, p) for n, p in self.named_parameters() if n.startswith(mine)]
         names = tuple(n for n, _ in named)
         len_dev = lengths.to(device=src.device, dtype=torch.int64).contiguous()
-        return _EncoderTrainFn.apply(self, src.contiguous().float(), len_dev, names, *[p for _, p in named])
+        return _EncoderTrainFn.apply(self, src.contiguous().float(), len_dev, names, want_taps, *[p for _, p in named])
 
     def _forward_heads_trainable(self, src: Tensor, lengths: Tensor) -> Tensor:
         """First slice of the training path (train.py:53-70): the exit heads ``linears.*`` are trainable on a FROZEN
@@ -694,7 +696,7 @@ class _EncoderTrainFn(torch.autograd.Function):
     runs at the reference's sites with probability ``model.dropout``."""
 
     @staticmethod
-    def forward(ctx, model, src, len_dev, names, *params):
+    def forward(ctx, model, src, len_dev, names, want_taps, *params):
         lib = capi.load()
         dev = src.device
         cfg = model._cfg
@@ -721,12 +723,14 @@ class _EncoderTrainFn(torch.autograd.Function):
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
             ws_ptr = (ws.data_ptr() + 255) // 256 * 256
             out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev)
+            taps = torch.empty((E, B, Tq, D), dtype=torch.float32, device=dev) if want_taps else None
             bn = torch.empty((E * L, 2, D), dtype=torch.float32, device=dev)
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             stream = torch.cuda.current_stream(dev).cuda_stream
             _trainer_check(lib.eec_train_forward(model._trainer, C.byref(pst), src.data_ptr(), len_dev.data_ptr(), B, T,
-                                                 int(model.train_passes), float(model.dropout), seed, out.data_ptr(), bn.data_ptr(),
-                                                 ws_ptr, nbytes, C.c_void_p(stream)), "eec_train_forward")
+                                                 int(model.train_passes), float(model.dropout), seed, out.data_ptr(),
+                                                 taps.data_ptr() if want_taps else None, bn.data_ptr(), ws_ptr, nbytes, C.c_void_p(stream)),
+                           "eec_train_forward")
             model._train_generation = getattr(model, "_train_generation", 0) + 1
             ctx.generation = model._train_generation
             # running statistics, as nn.BatchNorm1d(momentum=0.1) in train mode
@@ -744,19 +748,21 @@ class _EncoderTrainFn(torch.autograd.Function):
                         li += 1
         ctx.model, ctx.names, ctx.ws, ctx.ws_ptr, ctx.nbytes = model, names, ws, ws_ptr, nbytes
         ctx.keep = (src, len_dev)
+        ctx.want_taps = bool(want_taps)
         ctx.save_for_backward(out, *params)
-        return out
+        return (out, taps) if want_taps else out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g, g_taps=None):
         model, names = ctx.model, ctx.names
         if ctx.generation != model._train_generation:
             raise RuntimeError("the trainer records one forward at a time: run backward before the next training forward")
         out, params = ctx.saved_tensors[0], ctx.saved_tensors[1:]
         dev = out.device
         lib = capi.load()
-        g = g.contiguous().float()
+        g = torch.zeros_like(out) if g is None else g.contiguous().float()
+        g_taps = g_taps.contiguous().float() if g_taps is not None else None
         with torch.cuda.device(dev):
             tensors = dict(zip(names, params))
             for k, v in model.state_dict(keep_vars=True).items():
@@ -766,10 +772,11 @@ class _EncoderTrainFn(torch.autograd.Function):
             gst, gkeep = _params_struct(model, grads)
             stream = torch.cuda.current_stream(dev).cuda_stream
             _trainer_check(lib.eec_train_backward(model._trainer, C.byref(pst), C.byref(gst), out.data_ptr(), g.data_ptr(),
-                                                  ctx.ws_ptr, ctx.nbytes, C.c_void_p(stream)), "eec_train_backward")
+                                                  g_taps.data_ptr() if g_taps is not None else None, ctx.ws_ptr, ctx.nbytes,
+                                                  C.c_void_p(stream)), "eec_train_backward")
         ctx.ws = None
-        need = ctx.needs_input_grad[4:]
-        return (None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])
+        need = ctx.needs_input_grad[5:]
+        return (None, None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])
 
 
 class full_conformer(_HipEncoderMixin, nn.Module):
@@ -882,6 +889,12 @@ class full_conformer(_HipEncoderMixin, nn.Module):
         return self._decode_one(trg, enc, idx, log_softmax=True)
 
     def forward(self, src: Tensor, lengths: Tensor, trg: Tensor):
+        if self.training:
+            # train.py:36-52 (aed): encoder forward / backward on the HIP training kernels, the decoders (autograd through the
+            # reference's nn.TransformerDecoder on PyTorch-ROCm) consume the differentiable taps
+            enc_out, taps = Early_conformer._forward_train(self, src, lengths, want_taps=True)
+            dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
+            return dec_out, enc_out
         enc_out, taps, _ = self._run_encoder(src, lengths, want_taps=True)
         dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
         return dec_out, enc_out

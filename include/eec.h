@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 12
+#define EEC_ABI_VERSION 13
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -262,6 +262,8 @@ int eec_frontend_forward(eec_frontend* fe, const float* wave, const int64_t* len
  * eec_train_backward: `out` = the log-probs eec_train_forward returned, `grad_out` = dLoss/d out [E,B,T',V]; `grads` is
  * an eec_params whose pointers are WRITTEN (overwritten, not accumulated) with the gradient of the parameter at the same
  * position (pe / running_mean / running_var entries are ignored).  Gradient with respect to `mel` is not produced.
+ * `taps` (optional, [E][B*T'][D]) returns the group outputs the heads read -- what full_conformer feeds its attention decoders
+ * (early_exit.py:764-800); `grad_taps` (optional, same shape) is the gradient that arrived at them from outside the path.
  * A trainer is bound to the device that is current in its first eec_train_forward (eec_trainer_workspace_bytes is host
  * arithmetic and needs none), is not thread-safe, and holds ONE recorded forward at a time. */
 typedef struct eec_trainer eec_trainer;
@@ -270,10 +272,10 @@ int eec_trainer_create(const eec_config* cfg, eec_trainer** out);
 void eec_trainer_destroy(eec_trainer* tr);
 size_t eec_trainer_workspace_bytes(const eec_trainer* tr, int B, int T);
 int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* mel, const int64_t* lengths, int B, int T, int passes,
-                      float drop_prob, uint64_t seed, float* out, float* bn_batch_stats, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      float drop_prob, uint64_t seed, float* out, float* taps, float* bn_batch_stats, void* workspace,
+                      size_t workspace_bytes, void* stream);
 int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
-                       void* workspace, size_t workspace_bytes, void* stream);
+                       const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream);
 /* C = alpha * A . B^T (+ bias) on the training GEMM (test hook): A [M][K], B [N][K], C [M][N] fp32 row-major on the device */
 int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
                    int b_transposed, void* stream);

@@ -41,7 +41,7 @@ def run_gpu(model, mel, lens, prec="f16f8"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 12
+    assert lib.eec_abi_version() == 13
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 

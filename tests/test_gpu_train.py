@@ -14,7 +14,7 @@ import torch
 
 from conftest import base_kwargs
 from early_exit_transformer_amd import capi, synth
-from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses
+from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses, full_conformer
 from oracle import conformer_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -176,6 +176,63 @@ def test_train_mode_without_autograd_keeps_train_semantics():
     with torch.no_grad():
         ev = gpu(mel, lens)
     assert (ev - without).abs().max().item() > 1e-3
+
+
+def test_aed_training_step_matches_reference_modules():
+    """train.py:36-52 (decoder_mode aed) on full_conformer: encoder forward / backward on the HIP training kernels (the taps it
+    hands to the decoders are differentiable outputs of the same autograd function), decoders on PyTorch-ROCm autograd.
+    Against the same parameters run through the oracle encoder + the reference's decoder modules on the CPU (drop_prob 0):
+    CTC log-probs, decoder logits and the gradient of every parameter."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=256, n_head=8, d_feed_forward=256, depthwise_kernel_size=15, dec_voc_size=64)
+    common = dict(trg_pad_idx=30, enc_voc_size=64, max_len=400, features_length=80, drop_prob=0.0, n_dec_layers=2)
+    gpu = full_conformer(device="cuda", **common, **kw)
+    sd = G.aed_state_dict(gpu, 11)
+    gpu.load_state_dict(sd, strict=True)
+    cpu = full_conformer(device="cpu", **common, **kw)
+    cpu.load_state_dict(sd, strict=True)
+    ref_enc = R.EarlyConformerRef(**base_kwargs(drop_prob=0.0, dec_voc_size=64, enc_voc_size=64, max_len=400, **{k: v for k, v in kw.items() if k != "dec_voc_size"}))
+    enc_sd = {k.replace("linears_1.", "linears.").replace("positional_encoder_1.", "positional_encoder."): v for k, v in sd.items()
+              if k.startswith(("conv_subsample.", "conformer.", "linears_1.", "positional_encoder_1."))}
+    ref_enc.load_state_dict(enc_sd, strict=True)
+    ref_enc.train(), cpu.train(), gpu.cuda().train()
+    B, T = 3, 131
+    mel, lens = synth.synth_mel(B, 80, T, seed=2), torch.tensor([131, 100, 77])
+    g = torch.Generator().manual_seed(3)
+    trg = torch.randint(3, 64, (B, 7), generator=g)
+    trg[:, 0] = 1
+    trg[1, 5:] = 30
+    tgt, tl = synth.synth_targets(B, 6, 64, seed=2)
+    ce = torch.nn.CrossEntropyLoss(ignore_index=30)
+
+    # reference side: oracle encoder (taps through a hook on the Conformer groups) + the decoder modules of `cpu`
+    taps = []
+    hooks = [m.register_forward_hook(lambda _m, _i, o: taps.append(o[0] if isinstance(o, tuple) else o)) for m in ref_enc.conformer]
+    want_enc = ref_enc(mel, lens)
+    [h.remove() for h in hooks]
+    want_dec = torch.stack([cpu._decode_one(trg[:, :-1], taps[e], e) for e in range(2)])
+    want_loss = R.summed_exit_ctc_loss(want_enc, tgt, tl) + sum(ce(want_dec[e].reshape(-1, 64), trg[:, 1:].reshape(-1)) for e in range(2))
+    want_loss.backward()
+
+    dec_out, enc_out = gpu(mel.cuda(), lens, trg[:, :-1].cuda())
+    assert (enc_out.detach().cpu() - want_enc.detach()).abs().max().item() < 2e-4
+    assert (dec_out.detach().cpu() - want_dec.detach()).abs().max().item() < 2e-3
+    loss = exit_ctc_losses(enc_out, tgt, tl).sum() + sum(ce(dec_out[e].reshape(-1, 64), trg[:, 1:].cuda().reshape(-1)) for e in range(2))
+    assert abs(loss.item() - want_loss.item()) < 1e-3 * max(1.0, abs(want_loss.item()))
+    loss.backward()
+    want = {}
+    for n, p in ref_enc.named_parameters():
+        want[n.replace("linears.", "linears_1.")] = p.grad.double()
+    for n, p in cpu.named_parameters():
+        if p.grad is not None:
+            want[n] = p.grad.double()
+    got = {n: p.grad.detach().cpu().double() for n, p in gpu.named_parameters() if p.grad is not None}
+    assert set(want) <= set(got), sorted(set(want) - set(got))[:5]
+    compare_grads(got, want, 5e-3, "aed bf16x3")
 
 
 def test_reference_training_loop_reduces_the_loss():

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
     assert set(capi.EXPORTS) == declared
-    assert lib.eec_abi_version() == 12
+    assert lib.eec_abi_version() == 13
 
 
 def test_trainer_workspace_sizing_runs_without_a_device(lib):
