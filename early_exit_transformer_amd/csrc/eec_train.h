@@ -60,8 +60,6 @@ hipError_t launch_reduce_leading2(const float* part, int S, long n, float* out0,
 int colsum_blocks(int M);
 hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipStream_t st);
 
-hipError_t launch_silu_drop_fwd(const float* pre, float* act, long n, Drop d, hipStream_t st);          // act = drop(silu(pre))
-hipError_t launch_silu_drop_bwd(const float* dact, const float* pre, float* dpre, long n, Drop d, hipStream_t st);
 hipError_t launch_residual_drop_fwd(const float* r, const float* h, float scale, float* x, long n, Drop d, hipStream_t st);  // x = r + scale * drop(h)
 hipError_t launch_scale_drop(const float* dx, float scale, float* dh, long n, Drop d, hipStream_t st);   // dh = scale * dropmask * dx
 hipError_t launch_glu_fwd(const float* u, float* g, int M, int D, hipStream_t st);                        // g = u[:, :D] * sigmoid(u[:, D:])
@@ -84,7 +82,6 @@ hipError_t launch_bn_silu_bwd(const float* ds, const float* c, const float* stat
 // P[z][tq][:] = softmax(scale * S[z][tq][:] + (tk >= len[z / H] ? -inf : 0)) in place
 // Pd (optional): the dropped copy drop(P) written in the same pass
 hipError_t launch_softmax_fwd(float* S, float* Pd, const int32_t* key_len, int B, int H, int T, float scale, Drop d, hipStream_t st);
-hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream_t st);  // Pd = drop(P)
 // dS = scale * P * (dPd * dropmask - sum_k(dPd * dropmask * P)) in place over dP
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st);
 

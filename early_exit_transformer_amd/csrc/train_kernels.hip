@@ -600,20 +600,6 @@ hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipS
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
-__global__ __launch_bounds__(256) void silu_drop_fwd_kernel(const float* __restrict__ pre, float* __restrict__ act, long n, Drop d) {
-  const DropState ds(d);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float x = pre[i];
-    act[i] = x * sigmoidf_(x) * ds.mul((uint64_t)i);
-  }
-}
-__global__ __launch_bounds__(256) void silu_drop_bwd_kernel(const float* __restrict__ dact, const float* __restrict__ pre, float* __restrict__ dpre, long n, Drop d) {
-  const DropState ds(d);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float x = pre[i], s = sigmoidf_(x);
-    dpre[i] = dact[i] * ds.mul((uint64_t)i) * s * (1.0f + x * (1.0f - s));
-  }
-}
 __global__ __launch_bounds__(256) void residual_drop_fwd_kernel(const float* __restrict__ r, const float* __restrict__ h, float scale, float* __restrict__ x, long n, Drop d) {
   const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
@@ -627,14 +613,6 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
 static dim3 pw_grid(long n) { return dim3((unsigned)min((n + 255) / 256, (long)(256 * 16))); }
-hipError_t launch_silu_drop_fwd(const float* pre, float* act, long n, Drop d, hipStream_t st) {
-  hipLaunchKernelGGL(silu_drop_fwd_kernel, pw_grid(n), dim3(256), 0, st, pre, act, n, d);
-  return hipGetLastError();
-}
-hipError_t launch_silu_drop_bwd(const float* dact, const float* pre, float* dpre, long n, Drop d, hipStream_t st) {
-  hipLaunchKernelGGL(silu_drop_bwd_kernel, pw_grid(n), dim3(256), 0, st, dact, pre, dpre, n, d);
-  return hipGetLastError();
-}
 hipError_t launch_residual_drop_fwd(const float* r, const float* h, float scale, float* x, long n, Drop d, hipStream_t st) {
   hipLaunchKernelGGL(residual_drop_fwd_kernel, pw_grid(n), dim3(256), 0, st, r, h, scale, x, n, d);
   return hipGetLastError();
@@ -902,14 +880,6 @@ hipError_t launch_softmax_fwd(float* S, float* Pd, const int32_t* key_len, int B
   const long rows = (long)B * H * T;
   if (T <= 64 * kSmMax) hipLaunchKernelGGL(softmax_fwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, Pd, key_len, rows, H, T, scale, d);
   else hipLaunchKernelGGL(softmax_fwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, Pd, key_len, rows, H, T, scale, d);
-  return hipGetLastError();
-}
-__global__ __launch_bounds__(256) void drop_copy_kernel(const float* __restrict__ P, float* __restrict__ Pd, long n, Drop d) {
-  const DropState ds(d);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) Pd[i] = P[i] * ds.mul((uint64_t)i);
-}
-hipError_t launch_drop_copy(const float* P, float* Pd, long n, Drop d, hipStream_t st) {
-  hipLaunchKernelGGL(drop_copy_kernel, pw_grid(n), dim3(256), 0, st, P, Pd, n, d);
   return hipGetLastError();
 }
 template <bool REG>
