@@ -186,8 +186,8 @@ class _HipEncoderMixin:
             raise RuntimeError("the MI355X encoder runs on a HIP device only; move the model and inputs to "
                                "'cuda' (there is no CPU fallback -- the CPU reference lives in oracle/).")
         if self.training and torch.is_grad_enabled() and not getattr(self, "_frozen_encoder_pass", False):
-            raise NotImplementedError("training (autograd through the HIP encoder, batch-stat BatchNorm, dropout) "
-                                      "is not built yet; call under model.eval() / torch.no_grad()")
+            raise NotImplementedError("this class has no training step on the HIP path (Early_conformer and full_conformer do); "
+                                      "call under model.eval() / torch.no_grad()")
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
             raise ValueError(f"src must be [B, {self._cfg.n_mels}, T], got {tuple(src.shape)}")
         dev = src.device
@@ -284,7 +284,7 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         reuse this method (Splitformer, Early_zipformer, full_conformer) still raise for those."""
         trainable = [n for n, p in self.named_parameters() if p.requires_grad and not n.startswith("linears.")]
         if trainable:
-            raise NotImplementedError("only the exit heads (linears.*) can be trained yet: freeze the encoder "
+            raise NotImplementedError("this class trains its exit heads (linears.*) only: freeze the encoder "
                                       f"(requires_grad_(False)); trainable now: {trainable[:3]}{' ...' if len(trainable) > 3 else ''}")
         self._frozen_encoder_pass = True
         try:
@@ -467,7 +467,7 @@ class Early_zipformer(_HipEncoderMixin, nn.Module):
             raise RuntimeError("the MI355X encoder runs on a HIP device only (there is no CPU fallback -- the CPU "
                                "reference lives in oracle/).")
         if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training is not built yet; call under model.eval() / torch.no_grad()")
+            raise NotImplementedError("Early_zipformer has no training step on the HIP path; call under model.eval() / torch.no_grad()")
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels or src.size(2) < 3:
             raise ValueError(f"src must be [B, {self._cfg.n_mels}, T >= 3], got {tuple(src.shape)}")
         dev = src.device
