@@ -40,6 +40,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// sigmoid on the hardware reciprocal (1 ulp) instead of an IEEE division (a ~10-instruction sequence): the epilogues and
+// pointwise kernels evaluate it once per activation element
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // dropout
 // ---------------------------------------------------------------------------------------------------------------------
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           if (g.epi == EPI_DSILU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-              const float x = pre[sl][ps][j], sg = 1.0f / (1.0f + __expf(-x));
+              const float x = pre[sl][ps][j], sg = sigmoidf_(x);
               v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
             }
           }
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
           if (g.epi == EPI_SILU) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v2[j] = v[j] / (1.0f + __expf(-v[j])) * ds.mul((uint64_t)(ci + j));
+            for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * ds.mul((uint64_t)(ci + j));
             *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
           }
         } else {
@@ -377,12 +381,12 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
               float t = v[j];
               if (g.accumulate) t += C[ci + j];
               if (g.epi == EPI_DSILU) {
-                const float x = aux[ci + j], sg = 1.0f / (1.0f + __expf(-x));
+                const float x = aux[ci + j], sg = sigmoidf_(x);
                 t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
               }
               if (g.epi == EPI_RELU) t = fmaxf(t, 0.0f);
               C[ci + j] = t;
-              if (g.epi == EPI_SILU) C2[ci + j] = t / (1.0f + __expf(-t)) * ds.mul((uint64_t)(ci + j));
+              if (g.epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
             }
           }
         }
@@ -598,7 +602,6 @@ hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipS
 // ---------------------------------------------------------------------------------------------------------------------
 // pointwise
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 __global__ __launch_bounds__(256) void residual_drop_fwd_kernel(const float* __restrict__ r, const float* __restrict__ h, float scale, float* __restrict__ x, long n, Drop d) {
   const DropState ds(d);
