@@ -37,6 +37,10 @@ struct GemmArgs {
   float* C2;
   const float* aux;
   Drop drop;
+  // row sums of A over the contraction (A row-contiguous only): rowsum[(z / zdiv) * rowsum_z + m] = sum_k A[z](m, k) -- the bias
+  // gradient of a Linear falls out of its weight-gradient GEMM (A = dY^T) without another pass over dY
+  float* rowsum;
+  long rowsum_z;
 };
 inline GemmArgs gemm_args(const float* A, long a_m, long a_k, const float* B, long b_n, long b_k, float* C, long c_m, int M, int N, int K) {
   GemmArgs g{};

@@ -264,7 +264,19 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
       lb.load(rb, k0, K, tid);
     }
   };
+  // optional row sums of A (first column block only): every A element passes through this thread's registers exactly once
+  // (its BM / 32 groups of four all belong to the same four rows: 256 % (BM / 4) == 0)
+  float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  const bool do_rs = !AKC && g.rowsum != nullptr && blockIdx.x == 0;
   auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
+    if constexpr (!AKC) {
+      if (do_rs) {
+#pragma unroll
+        for (int it = 0; it < BM / 32; ++it)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rs[j] += ra[it][j];
+      }
+    }
     store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
     store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
     __syncthreads();
@@ -309,6 +321,23 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   };
   if (fast) k_loop(FastTag<true>{});
   else k_loop(FastTag<false>{});
+  if constexpr (!AKC) {
+    if (do_rs) {  // uniform over the workgroup.  The k-loop ended with a barrier: LDS is free.
+      constexpr int TPG = 256 / (BM / 4);  // threads that hold partial sums of the same four rows
+      float* red = (float*)smem;            // [TPG][BM]
+      const int rg = tid % (BM / 4), part = tid / (BM / 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[part * BM + 4 * rg + j] = rs[j];
+      __syncthreads();
+      if (tid < BM && m0 + tid < g.M) {
+        float t = 0.0f;
+#pragma unroll
+        for (int p2 = 0; p2 < TPG; ++p2) t += red[p2 * BM + tid];
+        g.rowsum[z0 * g.rowsum_z + m0 + tid] = t;
+      }
+      __syncthreads();
+    }
+  }
   // epilogue: the output tile leaves through LDS in slabs of 32 rows, so that every thread stores 16 contiguous bytes of a row
   // (an accumulator lane holds single columns: direct stores are 4-byte stores, four times as many instructions) and the
   // epilogue arithmetic runs on float4s.  The k-loop ended with a barrier: the planes are dead.
@@ -423,6 +452,7 @@ hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nz <= 0) return hipSuccess;
   if ((g.a_m != 1 && g.a_k != 1) || (g.b_n != 1 && g.b_k != 1)) return hipErrorInvalidValue;
   if (g.epi != EPI_NONE && (g.nz != 1 || g.accumulate)) return hipErrorInvalidValue;  // the epilogues index C as one [M][N] matrix
+  if (g.rowsum && (g.a_m != 1 || g.zdiv != 1)) return hipErrorInvalidValue;             // row sums: A row-contiguous, batch = splits
   auto wgs = [&](int bm, int bn) { return (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.nz; };
   // the largest tile that still gives every CU two workgroups
   if (g.N <= 32) return launch_gemm_t<1, 1, 4, 1>(g, np, st);  // 128 x 32
