@@ -60,6 +60,8 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const 
 hipError_t launch_reduce_leading(const float* part, int S, long stride, long n, float* out, hipStream_t st);
 // out0[j] = sum_s part[s][0][j], out1[j] = sum_s part[s][1][j], j < n  (part [S][2][n]: the LayerNorm / BatchNorm partials)
 hipError_t launch_reduce_leading2(const float* part, int S, long n, float* out0, float* out1, hipStream_t st);
+// general two-output form: columns [0, n0) of the n reduced columns go to out0, [n0, n) to out1
+hipError_t launch_reduce_leading_split(const float* part, int S, long stride, long n, long n0, float* out0, float* out1, hipStream_t st);
 // part[blk][n] = column sums of X[M][N] over the block's rows; blocks = colsum_blocks(M)
 int colsum_blocks(int M);
 hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipStream_t st);

@@ -118,17 +118,17 @@ void linear_bwd_weight(Run& r, const float* dy, const float* x, float* dW, float
   int chunk = ((M + S - 1) / S + 31) / 32 * 32;
   S = (M + chunk - 1) / chunk;
   GemmArgs g = gemm_args(dy, 1, N, x, 1, K, dW, K, N, K, chunk);
-  // the bias gradient = row sums of dY^T, taken inside the same GEMM (carved whether or not it is wanted: the sizing pass runs
-  // with null pointers and must see the same layout)
-  float* bpart = r.scr.f((size_t)S * N);
+  // the bias gradient = row sums of dY^T, taken inside the same GEMM and reduced over the splits in the same launch as dW
+  // (carved whether or not it is wanted: the sizing pass runs with null pointers and must see the same layout)
   if (S > 1) {
-    float* part = r.scr.f((size_t)S * N * K);
+    const long pstride = (long)N * K + N;  // one split's partial: [N][K] weight gradient, then [N] bias gradient
+    float* part = r.scr.f((size_t)S * pstride);
     g.C = part, g.nz = S, g.zdiv = 1, g.ktot = M;
-    g.a_z0 = (long)chunk * N, g.b_z0 = (long)chunk * K, g.c_z0 = (long)N * K;
-    if (db) g.rowsum = bpart, g.rowsum_z = N;
+    g.a_z0 = (long)chunk * N, g.b_z0 = (long)chunk * K, g.c_z0 = pstride;
+    if (db) g.rowsum = part + (long)N * K, g.rowsum_z = pstride;
     RUN(launch_gemm(g, r.tr->np, r.st));
-    RUN(launch_reduce_leading(part, S, (long)N * K, (long)N * K, dW, r.st));
-    if (db) RUN(launch_reduce_leading(bpart, S, N, N, db, r.st));
+    if (db) RUN(launch_reduce_leading_split(part, S, pstride, pstride, (long)N * K, dW, db, r.st));
+    else RUN(launch_reduce_leading(part, S, pstride, (long)N * K, dW, r.st));
   } else {
     g.K = M;
     if (db) g.rowsum = db, g.rowsum_z = 0;

@@ -591,6 +591,11 @@ hipError_t launch_reduce_leading(const float* part, int S, long stride, long n, 
   else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, stride, n, out, (float*)nullptr, 0L);
   return hipGetLastError();
 }
+hipError_t launch_reduce_leading_split(const float* part, int S, long stride, long n, long n0, float* out0, float* out1, hipStream_t st) {
+  if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, st, part, S, stride, n, out0, out1, n0);
+  else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, st, part, S, stride, n, out0, out1, n0);
+  return hipGetLastError();
+}
 hipError_t launch_reduce_leading2(const float* part, int S, long n, float* out0, float* out1, hipStream_t st) {
   if (S <= 32) hipLaunchKernelGGL(reduce_leading_kernel<4>, dim3((unsigned)((2 * n + 63) / 64)), dim3(256), 0, st, part, S, 2 * n, 2 * n, out0, out1, n);
   else hipLaunchKernelGGL(reduce_leading_kernel<16>, dim3((unsigned)((2 * n + 15) / 16)), dim3(256), 0, st, part, S, 2 * n, 2 * n, out0, out1, n);
