@@ -32,11 +32,13 @@ struct GemmArgs {
   float alpha;
   const float* bias;
   int accumulate;
-  // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux); 3: C = max(C, 0)
+  // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux); 3: C = max(C, 0);
+  // 4: C = aux + res_scale * drop(C)  (the residual connection around a sub-module)
   int epi;
   float* C2;
   const float* aux;
   Drop drop;
+  float res_scale;
   // row sums of A over the contraction (A row-contiguous only): rowsum[(z / zdiv) * rowsum_z + m] = sum_k A[z](m, k) -- the bias
   // gradient of a Linear falls out of its weight-gradient GEMM (A = dY^T) without another pass over dY
   float* rowsum;
@@ -66,7 +68,6 @@ hipError_t launch_reduce_leading_split(const float* part, int S, long stride, lo
 int colsum_blocks(int M);
 hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipStream_t st);
 
-hipError_t launch_residual_drop_fwd(const float* r, const float* h, float scale, float* x, long n, Drop d, hipStream_t st);  // x = r + scale * drop(h)
 hipError_t launch_scale_drop(const float* dx, float scale, float* dh, long n, Drop d, hipStream_t st);   // dh = scale * dropmask * dx
 hipError_t launch_glu_fwd(const float* u, float* g, int M, int D, hipStream_t st);                        // g = u[:, :D] * sigmoid(u[:, D:])
 hipError_t launch_glu_bwd(const float* dg, const float* u, float* du, int M, int D, hipStream_t st);

@@ -104,6 +104,13 @@ void linear_fwd(Run& r, const float* x, const float* W, const float* bias, float
   g.bias = bias;
   RUN(launch_gemm(g, r.tr->np, r.st));
 }
+// y[M][N] = r + scale * drop(x[M][K] . W[N][K]^T + bias): a sub-module's last Linear with its residual connection
+void linear_residual_fwd(Run& r, const float* x, const float* W, const float* bias, const float* res, float scale, uint32_t site, float* y, int M,
+                         int N, int K) {
+  GemmArgs g = gemm_args(x, K, 1, W, K, 1, y, N, M, N, K);
+  g.bias = bias, g.epi = 4, g.aux = res, g.res_scale = scale, g.drop = drop_of(r, site);
+  RUN(launch_gemm(g, r.tr->np, r.st));
+}
 // dx[M][K] (+)= dy[M][N] . W[N][K]
 void linear_bwd_data(Run& r, const float* dy, const float* W, float* dx, int M, int N, int K, bool accumulate = false) {
   GemmArgs g = gemm_args(dy, N, 1, W, 1, K, dx, K, M, K, N);
@@ -160,10 +167,8 @@ float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_
     RUN(launch_gemm(g, r.tr->np, r.st));
   }
   r.scr.reset();
-  float* h = r.scr.f((size_t)M * D);
-  linear_fwd(r, t.act, w2, b2, h, M, D, F);
   float* y = r.tape.f((size_t)M * D);
-  RUN(launch_residual_drop_fwd(x, h, 0.5f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_residual_fwd(r, t.act, w2, b2, x, 0.5f, t.site_res, y, M, D, F);
   return y;
 }
 
@@ -218,10 +223,8 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
       RUN(launch_gemm(g, tr->np, r.st));
     }
   }
-  float* o = r.scr.f((size_t)M * D);
-  linear_fwd(r, t.ctx, L.attn_out_w, L.attn_out_b, o, M, D, D);
   float* y = r.tape.f((size_t)M * D);
-  RUN(launch_residual_drop_fwd(x, o, 1.0f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_residual_fwd(r, t.ctx, L.attn_out_w, L.attn_out_b, x, 1.0f, t.site_res, y, M, D, D);
   return y;
 }
 
@@ -239,10 +242,8 @@ float* conv_fwd(Run& r, ConvTape& t, float* x, const eec_layer_params& L, float*
   float* part = r.scr.f((size_t)(colsum_blocks(M) + 1) * 2 * D);
   RUN(launch_bn_stats(t.c, M, D, part, t.stats, bn_mv, r.st));
   RUN(launch_bn_silu_fwd(t.c, t.stats, L.conv_bn_w, L.conv_bn_b, t.s, M, D, r.st));
-  float* v = r.scr.f((size_t)M * D);
-  linear_fwd(r, t.s, L.conv_pw2_w, L.conv_pw2_b, v, M, D, D);
   float* y = r.tape.f((size_t)M * D);
-  RUN(launch_residual_drop_fwd(x, v, 1.0f, y, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_residual_fwd(r, t.s, L.conv_pw2_w, L.conv_pw2_b, x, 1.0f, t.site_res, y, M, D, D);
   return y;
 }
 

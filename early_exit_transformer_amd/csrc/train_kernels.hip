@@ -208,7 +208,7 @@ struct FastTag {
 };
 
 // epilogue variants: C = v;  EPI_SILU: also C2 = drop(silu(v));  EPI_DSILU: C = v * dropmask * silu'(aux)
-enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3 };
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3, EPI_RESID = 4 };
 
 // STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
 // contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // ahead: the loads of slab s + 1 are in flight while slab s goes through LDS and out
   constexpr int NPS = 32 * (BN / 4) / 256;
   f32x4 pre[BM / 32][NPS];
-  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU);
+  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU || g.epi == EPI_RESID);
   const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
   auto request = [&](auto sl_tag) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_tag)::value;
@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
           }
+          if (g.epi == EPI_RESID) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = pre[sl][ps][j] + g.res_scale * v[j] * ds.mul((uint64_t)(ci + j));
+          }
           *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
           if (g.epi == EPI_SILU) {
 #pragma unroll
@@ -414,6 +418,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
                 t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
               }
               if (g.epi == EPI_RELU) t = fmaxf(t, 0.0f);
+              if (g.epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
               C[ci + j] = t;
               if (g.epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
             }
@@ -638,11 +643,6 @@ hipError_t launch_colsum_partial(const float* X, int M, int N, float* part, hipS
 // pointwise
 // ---------------------------------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void residual_drop_fwd_kernel(const float* __restrict__ r, const float* __restrict__ h, float scale, float* __restrict__ x, long n, Drop d) {
-  const DropState ds(d);
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-    x[i] = r[i] + scale * h[i] * ds.mul((uint64_t)i);
-}
 __global__ __launch_bounds__(256) void scale_drop_kernel(const float* __restrict__ dx, float scale, float* __restrict__ dh, long n, Drop d) {
   const DropState ds(d);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dh[i] = scale * dx[i] * ds.mul((uint64_t)i);
@@ -651,10 +651,6 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* __restrict__ y, const 
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
 static dim3 pw_grid(long n) { return dim3((unsigned)min((n + 255) / 256, (long)(256 * 16))); }
-hipError_t launch_residual_drop_fwd(const float* r, const float* h, float scale, float* x, long n, Drop d, hipStream_t st) {
-  hipLaunchKernelGGL(residual_drop_fwd_kernel, pw_grid(n), dim3(256), 0, st, r, h, scale, x, n, d);
-  return hipGetLastError();
-}
 hipError_t launch_scale_drop(const float* dx, float scale, float* dh, long n, Drop d, hipStream_t st) {
   hipLaunchKernelGGL(scale_drop_kernel, pw_grid(n), dim3(256), 0, st, dx, scale, dh, n, d);
   return hipGetLastError();
