@@ -29,6 +29,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -291,20 +292,6 @@ def main():
                 "algorithmic_flop_per_step": 3 * f_fwd,
                 "frac_of_mfma_peak": round(3 * f_fwd / d / MFMA_PEAK_FLOPS, 4) if ok else None, "error": err or None}
 
-    train = None
-    if not args.no_modes and not args.no_train:
-        n_tr = max(3, args.steps // 10)
-        lab4 = (f"CTC training step, default 12-layer d_model=256, batch {B}/GPU x {world} GPU(s), mel [80 x {T}] "
-                "(BASELINE.json configs[3]; gradients all-reduced in 64 MB buckets when N > 1)")
-        t_x3 = train_bench(CFG, 3, n_tr, lab4)
-        t_bf = train_bench(CFG, 1, n_tr, lab4)
-        t3 = None
-        if world == 1:
-            t3 = train_bench(dict(CFG, d_model=512, n_enc_layers=3), 1, max(2, n_tr // 2),
-                             f"CTC training step, 18-layer d_model=512 (6 exits x 3), batch {B}, mel [80 x {T}] (BASELINE.json configs[2])")
-        if rank == 0:
-            train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3}
-
     # ---- BASELINE.json configs[2] geometry (secondary line): 6 exits x 3 layers, d_model 512, forward + fused exit losses ----
     config3 = None
     if rank == 0 and world == 1 and not args.no_modes:
@@ -511,9 +498,44 @@ def main():
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
             "step_ms": step_ms, "modes": modes, "secondary_shapes": secondary, "config3": config3, "frontend": frontend,
-            "train_step": train, "aed_decode": aed,
+            "train_step": None, "aed_decode": aed,
         }
-        print(json.dumps(line), flush=True)
+    else:
+        line = None
+
+    # ---- training-step lines LAST, under a watchdog: every other number of the record is complete by now, and a collective
+    # that never returns on some rank (N > 1) must not take the headline line down with it ----
+    def emit(train_obj):
+        if rank == 0:
+            line["train_step"] = train_obj
+            print(json.dumps(line), flush=True)
+
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(float(os.environ.get("EEC_BENCH_TRAIN_TIMEOUT", "240"))):
+            emit({"error": "the training-step section did not finish in time (a rank or a collective hung); headline unaffected"})
+            sys.stdout.flush()
+            os._exit(0)
+
+    if not args.no_modes and not args.no_train:
+        threading.Thread(target=watchdog, daemon=True).start()
+        n_tr = max(3, args.steps // 10)
+        lab4 = (f"CTC training step, default 12-layer d_model=256, batch {B}/GPU x {world} GPU(s), mel [80 x {T}] "
+                "(BASELINE.json configs[3]; gradients all-reduced in 64 MB buckets when N > 1)")
+        t_x3 = train_bench(CFG, 3, n_tr, lab4)
+        t_bf = train_bench(CFG, 1, n_tr, lab4)
+        t3 = None
+        if world == 1:
+            t3 = train_bench(dict(CFG, d_model=512, n_enc_layers=3), 1, max(2, n_tr // 2),
+                             f"CTC training step, 18-layer d_model=512 (6 exits x 3), batch {B}, mel [80 x {T}] (BASELINE.json configs[2])")
+        if rank == 0:
+            train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3}
+
+        done.set()
+        emit(train if rank == 0 else None)
+    else:
+        emit(None)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
