@@ -7,6 +7,8 @@
 //   x += 0.5 * drop(W2 . drop(silu(W1 . LN(x))));  x += drop(out_proj(MHA(LN(x), attention-prob dropout)));
 //   x += drop(pw2 . silu(BN_batch(dw(GLU(pw1 . LN(x))))));  x += 0.5 * ffn2(x);  x = LN(x)
 // stem: Conv1d(k3, s2) o Conv1d(k3, s2) (no activation), + positional encoding, dropout (early_exit.py:24-48, 617-623).
+#include <stdlib.h>
+
 #include <algorithm>
 #include <string>
 #include <vector>
@@ -75,6 +77,9 @@ struct eec_trainer {
   int32_t* key_len = nullptr;
   uint32_t site_pe = 0;
   size_t tape_bytes = 0;
+  // weight-gradient GEMMs run on a second stream, beside the dX chain they do not feed (created at the first backward)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_main = nullptr, ev_side = nullptr;
 };
 
 namespace {
@@ -83,7 +88,9 @@ struct Run {
   eec_trainer* tr;
   bool dry;
   hipStream_t st;
-  Bump tape, scr;
+  Bump tape, scr, sscr;  // sscr: scratch of the side stream (split-K partials), never shared with the main stream's
+  hipStream_t side = nullptr;
+  bool side_busy = false;
   hipError_t err = hipSuccess;
   const char* where = "";
   uint32_t site = 1;
@@ -97,6 +104,30 @@ struct Run {
   } while (0)
 
 Drop drop_of(const Run& r, uint32_t site) { return Drop{r.tr->p, r.tr->seed, site}; }
+
+// Side stream protocol.  A weight-gradient job reads its dY (main-stream scratch) and x (tape) operands: it starts after
+// everything the main stream has enqueued so far (side_begin) and the main stream must not overwrite or recycle those
+// scratch buffers before it has finished -- backward modules therefore never write into a buffer they handed to a job, and
+// join_side() precedes every recycling of the main scratch (module starts) and the end of the backward.
+void side_begin(Run& r) {
+  if (r.dry || !r.side) return;
+  RUN(hipEventRecord(r.tr->ev_main, r.st));
+  RUN(hipStreamWaitEvent(r.side, r.tr->ev_main, 0));
+}
+void side_end(Run& r) {
+  if (r.dry || !r.side) return;
+  RUN(hipEventRecord(r.tr->ev_side, r.side));
+  r.side_busy = true;
+}
+void join_side(Run& r) {
+  if (r.dry || !r.side || !r.side_busy) return;
+  RUN(hipStreamWaitEvent(r.st, r.tr->ev_side, 0));
+  r.side_busy = false;
+}
+void bwd_scratch_reset(Run& r) {
+  join_side(r);
+  r.scr.reset();
+}
 
 // y[M][N] = x[M][K] . W[N][K]^T + bias
 void linear_fwd(Run& r, const float* x, const float* W, const float* bias, float* y, int M, int N, int K) {
@@ -119,29 +150,31 @@ void linear_bwd_data(Run& r, const float* dy, const float* W, float* dx, int M, 
 }
 // dW[N][K] = dy[M][N]^T . x[M][K] (split over the rows, partials summed in a fixed order); db[N] = column sums of dy
 void linear_bwd_weight(Run& r, const float* dy, const float* x, float* dW, float* db, int M, int N, int K) {
-  const size_t mark = r.scr.off;
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   int S = std::max(1, std::min(512 / tiles, M / 64));
   int chunk = ((M + S - 1) / S + 31) / 32 * 32;
   S = (M + chunk - 1) / chunk;
+  hipStream_t ws = r.side ? r.side : r.st;
+  side_begin(r);
+  r.sscr.reset();  // jobs are ordered on their stream: the previous one's partials are consumed before these are written
   GemmArgs g = gemm_args(dy, 1, N, x, 1, K, dW, K, N, K, chunk);
   // the bias gradient = row sums of dY^T, taken inside the same GEMM and reduced over the splits in the same launch as dW
   // (carved whether or not it is wanted: the sizing pass runs with null pointers and must see the same layout)
   if (S > 1) {
     const long pstride = (long)N * K + N;  // one split's partial: [N][K] weight gradient, then [N] bias gradient
-    float* part = r.scr.f((size_t)S * pstride);
+    float* part = r.sscr.f((size_t)S * pstride);
     g.C = part, g.nz = S, g.zdiv = 1, g.ktot = M;
     g.a_z0 = (long)chunk * N, g.b_z0 = (long)chunk * K, g.c_z0 = pstride;
     if (db) g.rowsum = part + (long)N * K, g.rowsum_z = pstride;
-    RUN(launch_gemm(g, r.tr->np, r.st));
-    if (db) RUN(launch_reduce_leading_split(part, S, pstride, pstride, (long)N * K, dW, db, r.st));
-    else RUN(launch_reduce_leading(part, S, pstride, (long)N * K, dW, r.st));
+    RUN(launch_gemm(g, r.tr->np, ws));
+    if (db) RUN(launch_reduce_leading_split(part, S, pstride, pstride, (long)N * K, dW, db, ws));
+    else RUN(launch_reduce_leading(part, S, pstride, (long)N * K, dW, ws));
   } else {
     g.K = M;
     if (db) g.rowsum = db, g.rowsum_z = 0;
-    RUN(launch_gemm(g, r.tr->np, r.st));
+    RUN(launch_gemm(g, r.tr->np, ws));
   }
-  r.scr.reset(mark);
+  side_end(r);
 }
 // dx = dx + LN'(dln) in place; dg / db from the per-block partials
 void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const float* mean, const float* rstd, float* dx, bool add_res, float* dg,
@@ -292,9 +325,10 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
 void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float* w1, const float* w2, float* g_ln_w, float* g_ln_b, float* g_w1,
              float* g_b1, float* g_w2, float* g_b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
-  r.scr.reset();
+  bwd_scratch_reset(r);
   float* dh = r.scr.f((size_t)M * D);
   float* dpre = r.scr.f((size_t)M * F);
+  float* dln = r.scr.f((size_t)M * D);  // its own buffer: dh is still being read by the dW2 job
   RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
   linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
   {  // dpre = (dh . W2) * dropmask * silu'(pre), the activation's backward in the GEMM epilogue
@@ -303,8 +337,8 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
     RUN(launch_gemm(g, r.tr->np, r.st));
   }
   linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
-  linear_bwd_data(r, dpre, w1, dh, M, F, D);  // dh now holds d LN-output
-  ln_bwd(r, dh, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
+  linear_bwd_data(r, dpre, w1, dln, M, F, D);
+  ln_bwd(r, dln, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
 }
 
 void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, eec_layer_params& G) {
@@ -313,8 +347,9 @@ void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, e
   const int M = tr->M, D = a.D, Tq = a.Tq;
   const long np_ = (long)a.B * a.H * Tq * Tq;
   const bool fused = attn_fused_supported(D, a.H);
-  r.scr.reset();
+  bwd_scratch_reset(r);
   float* d_o = r.scr.f((size_t)M * D);
+  float* dln = r.scr.f((size_t)M * D);  // its own buffer: d_o is still being read by the out_proj weight-gradient job
   float* dctx = r.scr.f((size_t)M * D);
   float* dqkv = r.scr.f((size_t)M * 3 * D);
   float* dP = fused ? r.scr.f((size_t)a.B * a.H * Tq) : r.scr.f((size_t)np_);  // fused: the per-row delta instead
@@ -348,15 +383,16 @@ void attn_bwd(Run& r, const AttnTape& t, float* dx, const eec_layer_params& L, e
     }
   }
   linear_bwd_weight(r, dqkv, t.ln, (float*)G.attn_in_w, (float*)G.attn_in_b, M, 3 * D, D);
-  linear_bwd_data(r, dqkv, L.attn_in_w, d_o, M, 3 * D, D);  // d_o now holds d LN-output
-  ln_bwd(r, d_o, t.x, L.attn_ln_w, t.mean, t.rstd, dx, true, (float*)G.attn_ln_w, (float*)G.attn_ln_b, M, D);
+  linear_bwd_data(r, dqkv, L.attn_in_w, dln, M, 3 * D, D);
+  ln_bwd(r, dln, t.x, L.attn_ln_w, t.mean, t.rstd, dx, true, (float*)G.attn_ln_w, (float*)G.attn_ln_b, M, D);
 }
 
 void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, eec_layer_params& G) {
   const eec_trainer* tr = r.tr;
   const int M = tr->M, D = tr->cfg.d_model, K = tr->cfg.dw_kernel;
-  r.scr.reset();
+  bwd_scratch_reset(r);
   float* dv = r.scr.f((size_t)M * D);
+  float* dln = r.scr.f((size_t)M * D);  // its own buffer: dv is still being read by the pointwise-2 weight-gradient job
   float* ds = r.scr.f((size_t)M * D);
   float* dc = r.scr.f((size_t)M * D);
   float* du = r.scr.f((size_t)M * 2 * D);
@@ -378,8 +414,8 @@ void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, e
   RUN(launch_dw_bwd_data(dc, L.conv_dw_w, ds, tr->B, tr->Tq, D, K, r.st));  // ds now holds d GLU-output
   RUN(launch_glu_bwd(ds, t.u, du, M, D, r.st));
   linear_bwd_weight(r, du, t.ln, (float*)G.conv_pw1_w, (float*)G.conv_pw1_b, M, 2 * D, D);
-  linear_bwd_data(r, du, L.conv_pw1_w, dv, M, 2 * D, D);  // dv now holds d LN-output
-  ln_bwd(r, dv, t.x, L.conv_ln_w, t.mean, t.rstd, dx, true, (float*)G.conv_ln_w, (float*)G.conv_ln_b, M, D);
+  linear_bwd_data(r, du, L.conv_pw1_w, dln, M, 2 * D, D);
+  ln_bwd(r, dln, t.x, L.conv_ln_w, t.mean, t.rstd, dx, true, (float*)G.conv_ln_w, (float*)G.conv_ln_b, M, D);
 }
 
 void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out, const float* grad_taps) {
@@ -390,7 +426,7 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
   float* dx = r.tape.f((size_t)M * D);
   for (int e = c.n_exits - 1; e >= 0; --e) {
     const float* tap = tr->lt[(e + 1) * c.layers_per_exit - 1].out;
-    r.scr.reset();
+    bwd_scratch_reset(r);
     float* dlogits = r.scr.f((size_t)M * V);
     RUN(eec::launch_logsoftmax_backward(out + (size_t)e * M * V, grad_out + (size_t)e * M * V, M, V, dlogits, r.st));
     linear_bwd_weight(r, dlogits, tap, (float*)Gp->head_w[e], (float*)Gp->head_b[e], M, V, D);
@@ -411,7 +447,7 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
     }
   }
   // stem
-  r.scr.reset();
+  bwd_scratch_reset(r);
   float* dx0 = r.scr.f((size_t)M * D);
   float* Gc = r.scr.f((size_t)M * 3 * D);
   float* dout1 = r.scr.f((size_t)B * T1 * D);
@@ -438,6 +474,7 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
   }
   RUN(launch_col2im_stride2(Gc, dout1, B, T1, Tq, D, r.st));
   linear_bwd_weight(r, dout1, tr->a1, (float*)Gp->sub0_w, (float*)Gp->sub0_b, B * T1, D, 3 * C);
+  join_side(r);  // every gradient is complete in main-stream order
 }
 
 int check_trainer_cfg(const eec_config& c) {
@@ -470,7 +507,13 @@ int eec_trainer_create(const eec_config* cfg, eec_trainer** out) {
   *out = tr;
   return 0;
 }
-void eec_trainer_destroy(eec_trainer* tr) { delete tr; }
+void eec_trainer_destroy(eec_trainer* tr) {
+  if (!tr) return;
+  if (tr->side) (void)hipStreamDestroy(tr->side);
+  if (tr->ev_main) (void)hipEventDestroy(tr->ev_main);
+  if (tr->ev_side) (void)hipEventDestroy(tr->ev_side);
+  delete tr;
+}
 
 size_t eec_trainer_workspace_bytes(const eec_trainer* tr_in, int B, int T) {
   if (!tr_in) return 0;
@@ -485,7 +528,7 @@ size_t eec_trainer_workspace_bytes(const eec_trainer* tr_in, int B, int T) {
   const size_t fwd_scr = r.scr.peak;
   r.scr = Bump{};
   backward(r, &P, &P, nullptr, nullptr, nullptr);
-  return (r.tape.peak + 256) + std::max(fwd_scr, r.scr.peak) + 4096;
+  return (r.tape.peak + 256) + (r.sscr.peak + 256) + std::max(fwd_scr, r.scr.peak) + 4096;
 }
 
 int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* mel, const int64_t* lengths, int B, int T, int passes,
@@ -538,20 +581,35 @@ int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_para
   // the residual-stream gradient is carved from the head of the scratch region through `tape` (kept for the whole backward)
   r.tape.base = (char*)workspace + tr->tape_bytes;
   const size_t dx_bytes = ((size_t)tr->M * tr->cfg.d_model * sizeof(float) + 511) / 256 * 256;
-  r.scr.base = (char*)workspace + tr->tape_bytes + dx_bytes;
-  if (workspace_bytes < tr->tape_bytes + dx_bytes) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
-  r.tape.cap = dx_bytes, r.scr.cap = workspace_bytes - tr->tape_bytes - dx_bytes;
-  {  // the scratch need of this backward, before any launch
+  size_t side_bytes = 0;
+  {  // the scratch needs of this backward, before any launch: [tape][dx][side-stream scratch][main scratch]
     eec_trainer tmp = *tr;
     Run d{&tmp, true, nullptr};
     backward(d, params, grads, out, grad_out, grad_taps);
-    if (d.scr.peak > r.scr.cap || d.tape.peak > r.tape.cap)
+    side_bytes = (d.sscr.peak + 255) / 256 * 256;
+    if (workspace_bytes < tr->tape_bytes + dx_bytes + side_bytes || d.scr.peak > workspace_bytes - tr->tape_bytes - dx_bytes - side_bytes ||
+        d.tape.peak > dx_bytes)
       return tfail(EEC_ERR_WORKSPACE, "workspace too small for the backward scratch: need " + std::to_string(d.scr.peak) + " + " +
-                                          std::to_string(d.tape.peak) + ", have " + std::to_string(r.scr.cap) + " + " + std::to_string(r.tape.cap) +
-                                          " (workspace " + std::to_string(workspace_bytes) + ", tape " + std::to_string(tr->tape_bytes) + ")");
+                                          std::to_string(d.sscr.peak) + " + " + std::to_string(d.tape.peak) + " beside the tape of " +
+                                          std::to_string(tr->tape_bytes) + ", workspace " + std::to_string(workspace_bytes));
   }
+  const char* no_side = getenv("EEC_TRAIN_NO_SIDE");  // diagnostic: every job on the main stream (results are bit-identical)
+  if (no_side && no_side[0] == '1') {
+    r.side = nullptr;
+  } else if (!tr->side) {  // a failure here only means the jobs run on the main stream
+    if (hipStreamCreateWithFlags(&tr->side, hipStreamNonBlocking) != hipSuccess) tr->side = nullptr;
+    if (tr->side && (hipEventCreateWithFlags(&tr->ev_main, hipEventDisableTiming) != hipSuccess ||
+                     hipEventCreateWithFlags(&tr->ev_side, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipStreamDestroy(tr->side);
+      tr->side = nullptr;
+    }
+  }
+  if (!(no_side && no_side[0] == '1')) r.side = tr->side;
+  r.sscr.base = (char*)workspace + tr->tape_bytes + dx_bytes, r.sscr.cap = side_bytes;
+  r.scr.base = (char*)workspace + tr->tape_bytes + dx_bytes + side_bytes;
+  r.tape.cap = dx_bytes, r.scr.cap = workspace_bytes - tr->tape_bytes - dx_bytes - side_bytes;
   backward(r, params, grads, out, grad_out, grad_taps);
-  if (r.tape.overflow || r.scr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
+  if (r.tape.overflow || r.scr.overflow || r.sscr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   return 0;
 }

@@ -238,6 +238,34 @@ def test_aed_training_step_matches_reference_modules():
     compare_grads(got, want, 5e-3, "aed bf16x3")
 
 
+def test_side_stream_weight_gradients_are_bit_identical_to_the_single_stream_order():
+    """The weight-gradient GEMMs run on a second stream beside the dX chain.  The arithmetic is the same either way, so every
+    gradient must be BIT-identical to a run with the jobs on the main stream (EEC_TRAIN_NO_SIDE=1), repeatedly, at a size where
+    the two streams really overlap: a missed dependency shows up as a mismatch."""
+    import os
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=2, d_feed_forward=1024)
+    _, gpu = make_train_pair(kw, seed=17, drop=0.1)
+    mel, lens = synth.synth_mel(16, 80, 1027, seed=17).cuda(), torch.tensor([1027] * 8 + [900, 800, 700, 600, 500, 400, 300, 200])
+    tgt, tl = synth.synth_targets(16, 20, 256, seed=17)
+
+    def grads():
+        torch.manual_seed(5)
+        gpu.zero_grad(set_to_none=True)
+        exit_ctc_losses(gpu(mel, lens), tgt, tl).sum().backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in gpu.named_parameters()}
+
+    os.environ["EEC_TRAIN_NO_SIDE"] = "1"
+    try:
+        want = grads()
+    finally:
+        del os.environ["EEC_TRAIN_NO_SIDE"]
+    for rep in range(6):
+        got = grads()
+        bad = [n for n in want if not torch.equal(got[n], want[n])]
+        assert not bad, (rep, bad[:4])
+
+
 def test_reference_training_loop_reduces_the_loss():
     """The loop of train.py:27-75 (AdamW, clip_grad_norm_, summed per-exit CTC loss) on the product module."""
     kw = base_kwargs(**SMALL)
