@@ -225,11 +225,23 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   bf16* a_lo = NP == 3 ? b_hi + EB : a_hi;
   bf16* b_lo = NP == 3 ? a_lo + EA : b_hi;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
-  const int z0 = blockIdx.z / g.zdiv, z1 = blockIdx.z % g.zdiv;
+  // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest, then y, z), each XCD with
+  // its own L2: taken naively, the column blocks of one row tile -- which all read the same A rows -- land on eight different
+  // L2s and every one of them fetches those rows (measured on the default model: 98 GB of L2-miss reads per training step).
+  // Instead XCD x owns the CONTIGUOUS range [x, x + 1) * total / 8 of the tile order, so that tiles sharing operands share an L2.
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const unsigned nbx = gridDim.x, nby = gridDim.y, total = nbx * nby * gridDim.z;
+    if ((total & 7u) == 0) {
+      const unsigned l = bx + nbx * (by + nby * bz), t = (l & 7u) * (total >> 3) + (l >> 3);
+      bx = t % nbx, by = (t / nbx) % nby, bz = t / (nbx * nby);
+    }
+  }
+  const int z0 = bz / g.zdiv, z1 = bz % g.zdiv;
   const float* __restrict__ A = g.A + z0 * g.a_z0 + z1 * g.a_z1;
   const float* __restrict__ B = g.B + z0 * g.b_z0 + z1 * g.b_z1;
   float* __restrict__ C = g.C + z0 * g.c_z0 + z1 * g.c_z1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = by * BM, n0 = bx * BN;
   const long a_r = AKC ? g.a_m : 1, a_s = AKC ? 1 : g.a_k;  // (row stride, k stride) as load_tile wants them
   const long b_r = BKC ? g.b_n : 1, b_s = BKC ? 1 : g.b_k;
   f32x16 acc[TM][TN];
@@ -251,7 +263,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // k-tiles are walked in a rotated order that differs between neighbouring workgroups: with power-of-two leading
   // dimensions the rows of a k-contiguous tile all fall on the same few L2 / HBM channels for a given k offset, and
   // workgroups in lockstep would all hit those at once (measured: 101 -> TFLOP/s class of the transposed layouts)
-  const int rot = (int)((blockIdx.x * 3 + blockIdx.y + blockIdx.z) % (unsigned)nk);
+  const int rot = (int)((bx * 3 + by + bz) % (unsigned)nk);
   auto k_of = [&](int kt) __attribute__((always_inline)) { const int t = kt + rot; return (t >= nk ? t - nk : t) * kBK; };
   // fast: every tile of both operands is a full, aligned interior tile -- the loop then carries no bounds logic at all
   const bool fast = la.clean && lb.clean && (K % kBK) == 0;
@@ -267,7 +279,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // optional row sums of A (first column block only): every A element passes through this thread's registers exactly once
   // (its BM / 32 groups of four all belong to the same four rows: 256 % (BM / 4) == 0)
   float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  const bool do_rs = !AKC && g.rowsum != nullptr && blockIdx.x == 0;
+  const bool do_rs = !AKC && g.rowsum != nullptr && bx == 0;
   auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
     if constexpr (!AKC) {
       if (do_rs) {
