@@ -77,6 +77,8 @@ def compare_grads(got, want, tol, label):
     (dict(SMALL, n_head=2, depthwise_kernel_size=31, d_feed_forward=96), 5, 79, [79, 79, 60, 41, 30]),  # head dim 32, T' = 19
     (dict(n_enc_exits=2, n_enc_layers=1, d_feed_forward=512), 2, 259, [259, 170]),
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=2, d_feed_forward=256, depthwise_kernel_size=31), 2, 99, [99, 64]),
+    (dict(SMALL, n_head=2), 2, 47, [47, 30]),  # T' = 11: fused attention with a single, ragged key tile
+    (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=64), 1, 51, [51]),  # a single utterance: BatchNorm over its 12 frames
     # the benchmark's frame count (T' = 256: two query / key blocks of the fused attention per head, eight key tiles, ragged keys)
     (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 700]),
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 513]),
