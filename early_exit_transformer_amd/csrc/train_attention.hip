@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
 // backward, pass over key tiles: dV[k][d] = sum_q P_drop[q][k] dO[q][d],  dK[k][d] = sum_q dS[q][k] Q[q][d]
 // ---------------------------------------------------------------------------------------------------------------------
 template <int DH, int NP>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
+__global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const int32_t* __restrict__ key_len, const float* __restrict__ d_o,
                                                               const float* __restrict__ lse, const float* __restrict__ delta, float* __restrict__ dqkv,
                                                               int H, int Tq, int D, float scale, Drop drop) {
   constexpr int KSQ = DH / 16, DT = DH / 32;
