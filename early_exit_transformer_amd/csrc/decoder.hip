@@ -85,9 +85,7 @@ int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, i
   hipStream_t st = (hipStream_t)stream;
   const int D = g.D, H = g.H, dh = g.dh, M = Bm * S, Mk = Bm * Tq;
   const float scale = 1.0f / sqrtf((float)dh);
-  float mean_unused = 0;  // LayerNorm statistics are not kept: they go to the tail of the h buffer
-  (void)mean_unused;
-  float* stats = b.h;  // [2][M] scratch (h is free whenever a LayerNorm runs)
+  float* stats = b.h;  // LayerNorm statistics are not kept: [2][M] scratch in the h buffer, which is free whenever a LayerNorm runs
   auto linear = [&](const float* x, const float* W, const float* bias, float* y, int m, int n, int k, int epi, bool accumulate) {
     GemmArgs a = gemm_args(x, k, 1, W, k, 1, y, n, m, n, k);
     a.bias = bias, a.epi = epi, a.accumulate = accumulate ? 1 : 0;
