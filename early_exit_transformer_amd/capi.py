@@ -161,7 +161,7 @@ def load() -> C.CDLL:
     lib.eec_decoder_workspace_bytes.argtypes = [C.c_int] * 7
     lib.eec_decoder_workspace_bytes.restype = C.c_size_t
     lib.eec_decoder_forward.argtypes = [C.POINTER(EecDecoderParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
-                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
     _lib = lib

@@ -70,8 +70,8 @@ size_t eec_decoder_workspace_bytes(int d_model, int n_heads, int d_ff, int vocab
 }
 
 int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* trg,
-                        const float* enc, int Bm, int S, int Tq, int passes, int log_softmax, float* out, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        const float* enc, int Bm, int S, int Tq, int enc_shared, int passes, int log_softmax, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream) {
   if (!p || !trg || !enc || !out || !workspace || !p->layers) return dfail(EEC_ERR_BAD_ARG, "null argument");
   if (passes != 1 && passes != 3) return dfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
   if (d_model <= 0 || d_model > 1024 || n_heads <= 0 || d_model % n_heads || vocab <= 0 || vocab > 1024 || p->n_layers <= 0 || Bm <= 0 || S <= 0 ||
@@ -83,7 +83,8 @@ int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, i
   const Bufs b = carve(c, g);
   if (c.overflow) return dfail(EEC_ERR_WORKSPACE, "workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  const int D = g.D, H = g.H, dh = g.dh, M = Bm * S, Mk = Bm * Tq;
+  const int D = g.D, H = g.H, dh = g.dh, M = Bm * S, Mk = (enc_shared ? 1 : Bm) * Tq;
+  const long mem_b = enc_shared ? 0 : (long)Tq * 2 * D;  // batch stride of the memory keys / values
   const float scale = 1.0f / sqrtf((float)dh);
   float* stats = b.h;  // LayerNorm statistics are not kept: [2][M] scratch in the h buffer, which is free whenever a LayerNorm runs
   auto linear = [&](const float* x, const float* W, const float* bias, float* y, int m, int n, int k, int epi, bool accumulate) {
@@ -115,7 +116,7 @@ int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, i
     DRUN(launch_ln_fwd(b.x, L.norm2_w, L.norm2_b, b.ln, stats, stats + M, M, D, st));
     DRUN(linear(b.ln, L.ca_in_w, L.ca_in_b, b.o, M, D, D, 0, false));                                   // q
     DRUN(linear(enc, L.ca_in_w + (size_t)D * D, L.ca_in_b + D, b.kv, Mk, 2 * D, D, 0, false));         // k | v of the memory
-    DRUN(attention(b.o, D, (long)S * D, b.kv, b.kv + D, 2 * D, (long)Tq * 2 * D, Tq, 0, nullptr));
+    DRUN(attention(b.o, D, (long)S * D, b.kv, b.kv + D, 2 * D, mem_b, Tq, 0, nullptr));
     DRUN(linear(b.ctx, L.ca_out_w, L.ca_out_b, b.x, M, D, D, 0, true));
     // feed-forward, ReLU
     DRUN(launch_ln_fwd(b.x, L.norm3_w, L.norm3_b, b.ln, stats, stats + M, M, D, st));

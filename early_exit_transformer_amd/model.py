@@ -869,14 +869,15 @@ class full_conformer(_HipEncoderMixin, nn.Module):
         d_ff, V = layer0.linear1.out_features, self.linears_2[idx].out_features
         with torch.cuda.device(dev):
             trg_c = trg.to(torch.int64).contiguous()
-            enc_c = enc.contiguous().float()
+            shared = Bm > 1 and enc.stride(0) == 0  # beam search: one utterance expanded over the beams (util/beam_infer.py:233)
+            enc_c = (enc[:1] if shared else enc).contiguous().float()
             nbytes = lib.eec_decoder_workspace_bytes(cfg.d_model, cfg.n_heads, d_ff, V, Bm, S, Tq)
             ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
             ws_ptr = (ws.data_ptr() + 255) // 256 * 256
             out = torch.empty((Bm, S, V), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
             rc = lib.eec_decoder_forward(C.byref(ps), cfg.d_model, cfg.n_heads, d_ff, V, int(self.trg_pad_idx), trg_c.data_ptr(),
-                                         enc_c.data_ptr(), Bm, S, Tq, int(self.decoder_passes), int(log_softmax), out.data_ptr(),
+                                         enc_c.data_ptr(), Bm, S, Tq, int(shared), int(self.decoder_passes), int(log_softmax), out.data_ptr(),
                                          ws_ptr, nbytes, C.c_void_p(stream))
             if rc != 0:
                 raise RuntimeError(f"eec_decoder_forward failed (code {rc}): {lib.eec_decoder_last_error().decode(errors='replace')}")

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 13
+#define EEC_ABI_VERSION 14
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -286,7 +286,8 @@ int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, 
  * cross-attention over enc [Bm][Tq][D], ReLU feed-forward) and the shared final LayerNorm.  fp32 parameters are read in
  * place (state_dict tensors); arithmetic as the training GEMM (passes 3: bf16 hi/lo split, ~1e-5 of fp32).  trg: int64
  * [Bm][S]; positions equal to pad_idx are masked as keys.  The caller's beam search (util/beam_infer.py:198-307) stays
- * above this call: one call per decoding step, as the reference (no KV cache). */
+ * above this call: one call per decoding step, as the reference (no KV cache).  enc_shared != 0: every one of the Bm rows attends
+ * to the SAME memory enc [1][Tq][D] (beam search expands one utterance over its beams): its keys / values are projected once. */
 typedef struct eec_decoder_layer_params {
   const float *sa_in_w, *sa_in_b;   /* self_attn.in_proj_{weight,bias}      [3D,D],[3D] */
   const float *sa_out_w, *sa_out_b; /* self_attn.out_proj.{weight,bias}     [D,D],[D]   */
@@ -306,8 +307,8 @@ typedef struct eec_decoder_params {
 const char* eec_decoder_last_error(void);
 size_t eec_decoder_workspace_bytes(int d_model, int n_heads, int d_ff, int vocab, int Bm, int S, int Tq);
 int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* trg,
-                        const float* enc, int Bm, int S, int Tq, int passes, int log_softmax, float* out, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        const float* enc, int Bm, int S, int Tq, int enc_shared, int passes, int log_softmax, float* out,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
     assert set(capi.EXPORTS) == declared
-    assert lib.eec_abi_version() == 13
+    assert lib.eec_abi_version() == 14
 
 
 def test_trainer_workspace_sizing_runs_without_a_device(lib):
@@ -61,7 +61,7 @@ def test_decoder_workspace_sizing_and_argument_checks(lib):
     assert lib.eec_decoder_workspace_bytes(256, 7, 2048, 256, 10, 5, 256) == 0  # d_model not divisible by the heads
     assert lib.eec_decoder_workspace_bytes(256, 8, 2048, 256, 0, 5, 256) == 0
     ps = capi.EecDecoderParams()
-    rc = lib.eec_decoder_forward(C.byref(ps), 256, 8, 2048, 256, 126, None, None, 1, 1, 1, 3, 1, None, None, 0, None)
+    rc = lib.eec_decoder_forward(C.byref(ps), 256, 8, 2048, 256, 126, None, None, 1, 1, 1, 0, 3, 1, None, None, 0, None)
     assert rc != 0 and b"null" in lib.eec_decoder_last_error()
 
 
