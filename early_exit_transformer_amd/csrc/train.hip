@@ -407,9 +407,12 @@ void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, e
     RUN(hipMemcpyAsync((void*)G.conv_bn_b, sums, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     RUN(hipMemcpyAsync((void*)G.conv_bn_w, sums + D, D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     r.scr.reset(mark);
-    float* wpart = r.scr.f((size_t)(dw_bwd_weight_blocks(tr->B, tr->Tq) + 1) * (K + 1) * D);
-    RUN(launch_dw_bwd_weight(dc, t.g, wpart, (float*)G.conv_dw_w, (float*)G.conv_dw_b, tr->B, tr->Tq, D, K, r.st));
-    r.scr.reset(mark);
+    // the depthwise taps' gradient is a weight-gradient job too: side stream, side scratch (dc is not written again in this module)
+    side_begin(r);
+    r.sscr.reset();
+    float* wpart = r.sscr.f((size_t)(dw_bwd_weight_blocks(tr->B, tr->Tq) + 1) * (K + 1) * D);
+    RUN(launch_dw_bwd_weight(dc, t.g, wpart, (float*)G.conv_dw_w, (float*)G.conv_dw_b, tr->B, tr->Tq, D, K, r.side ? r.side : r.st));
+    side_end(r);
   }
   RUN(launch_dw_bwd_data(dc, L.conv_dw_w, ds, tr->B, tr->Tq, D, K, r.st));  // ds now holds d GLU-output
   RUN(launch_glu_bwd(ds, t.u, du, M, D, r.st));
