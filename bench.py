@@ -505,10 +505,16 @@ def main():
 
     # ---- training-step lines LAST, under a watchdog: every other number of the record is complete by now, and a collective
     # that never returns on some rank (N > 1) must not take the headline line down with it ----
+    emit_lock, emitted = threading.Lock(), []
+
     def emit(train_obj):
-        if rank == 0:
-            line["train_step"] = train_obj
-            print(json.dumps(line), flush=True)
+        with emit_lock:  # exactly one record, whichever of the main thread and the watchdog gets here first
+            if emitted:
+                return
+            emitted.append(True)
+            if rank == 0:
+                line["train_step"] = train_obj
+                print(json.dumps(line), flush=True)
 
     done = threading.Event()
 
