@@ -334,17 +334,25 @@ def main():
             spec, vlen = mel[0], torch.tensor(T)
             inf = BeamInference()
             kw5 = dict(vocab_size=CFG["dec_voc_size"], SOS_token=1, EOS_token=2, PAD_token=126, pen_alpha=1.0)
-            inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            hyps = inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5)
-            torch.cuda.synchronize()
-            d = time.perf_counter() - t1
+            def timed(**more):
+                inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5, **more)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                hyps = inf.decode_all_exits(fc, spec, vlen, beam_size=10, **kw5, **more)
+                torch.cuda.synchronize()
+                return time.perf_counter() - t1, hyps
+            d, hyps = timed()
+            d_full, hyps_full = timed(kv_cache=False)  # the reference's way: the decoder re-run on the whole prefix at every step
             steps5 = int(T / 12)
             aed = {"workload": f"full_conformer (6 x 2 encoder, 6 decoder layers per exit), 1 utterance of {T} mel frames: encoder once, "
-                               f"beam search (beam 10, {steps5} steps) for each of the 6 exits, decoder on eec_decoder_forward",
+                               f"beam search (beam 10, {steps5} steps) for each of the 6 exits, step-wise decoder over a key / value cache "
+                               "(eec_decoder_begin / eec_decoder_step)",
                    "seconds_per_utterance": round(d, 4), "decoder_steps": 6 * steps5, "ms_per_decoder_step": round(d / (6 * steps5) * 1e3, 3),
-                   "tokens_out": [len(h) for h in hyps]}
+                   "tokens_out": [len(h) for h in hyps],
+                   "whole_prefix_decoder": {"what": "same search, eec_decoder_forward on the whole prefix per step (no cache)",
+                                            "seconds_per_utterance": round(d_full, 4),
+                                            "ms_per_decoder_step": round(d_full / (6 * steps5) * 1e3, 3),
+                                            "same_best_beams": hyps == hyps_full}}
             del fc
             torch.cuda.empty_cache()
         except Exception as e:  # a secondary line never takes the headline down

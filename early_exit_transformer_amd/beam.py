@@ -8,8 +8,8 @@ serve without torchaudio.
   is the one with the highest accumulated score), but the candidate bookkeeping runs as tensor ops on the device
   instead of a Python loop over beams, and ``decode_all_exits`` runs the encoder ONCE for all exits (one
   ``eec_encoder_forward`` with taps) where the reference re-runs the first n exit groups for every n
-  (inference.py:44-46: O(E^2) groups per utterance).  The decoder itself stays the reference's
-  ``nn.TransformerDecoder`` on PyTorch-ROCm (model._decoder_).
+  (inference.py:44-46: O(E^2) groups per utterance), and the decoder advances step-wise over a key / value cache
+  (``model.decoder_session``, csrc/decoder_step.hip) where the reference re-runs it on the whole prefix per step.
 """
 from __future__ import annotations
 
@@ -67,9 +67,11 @@ class BeamInference:
     def beam_search(self, model, encoder_output: Tensor, layer_n: int, vocab_size: Optional[int] = None, max_length: int = 500,
                     min_length: int = 300, SOS_token: Optional[int] = None, EOS_token: Optional[int] = None,
                     PAD_token: Optional[int] = None, beam_size: Optional[int] = None, pen_alpha: Optional[float] = None,
-                    return_best_beam: bool = True):
+                    return_best_beam: bool = True, kv_cache: bool = True):
         """Returns ``(final_tokens, final_scores, best_tokens)`` like the reference: lists of 1-D token tensors / 0-D score
-        tensors, and the best beam as a Python list (SOS included)."""
+        tensors, and the best beam as a Python list (SOS included).  ``kv_cache`` (not in the reference): decode step-wise
+        through ``model.decoder_session`` (only the new position of every beam is computed; same log-probs to fp32
+        rounding) when the model offers one for this geometry; False re-runs ``_decoder_`` on the whole prefix per step."""
         V = self._arg(vocab_size, "dec_voc_size")
         sos, eos = self._arg(SOS_token, "trg_sos_idx"), self._arg(EOS_token, "trg_eos_idx")
         self._arg(PAD_token, "trg_pad_idx")  # accepted and unused, as in the reference
@@ -81,21 +83,33 @@ class BeamInference:
         scores = torch.zeros(1, dtype=torch.float32, device=dev)
         final_tokens: List[Tensor] = []
         final_scores: List[Tensor] = []
+        session = None
+        if kv_cache and max_length >= 1 and hasattr(model, "decoder_session") and encoder_output.size(0) == 1:
+            session = model.decoder_session(encoder_output, layer_n, max_length)
+            if session is not None and beam > session.max_beams:
+                session = None
+        parent: Optional[Tensor] = None
         i = -1
         for i in range(max_length):
-            enc = encoder_output if i == 0 else encoder_output.expand(tokens.size(0), *encoder_output.shape[1:])
-            logp = model._decoder_(tokens, enc, layer_n)[:, -1] / sequence_length_penalty(i + 1, alpha)
+            if session is not None:
+                logp = session.step(tokens[:, -1], parent)
+            else:
+                enc = encoder_output if i == 0 else encoder_output.expand(tokens.size(0), *encoder_output.shape[1:])
+                logp = model._decoder_(tokens, enc, layer_n)[:, -1]
+            logp = logp / sequence_length_penalty(i + 1, alpha)
             cand, idx = torch.topk((scores.unsqueeze(1) + logp).reshape(-1), count)
             beam_idx = torch.div(idx, V, rounding_mode="floor")
             tok_idx = torch.remainder(idx, V)
             grown = torch.cat([tokens[beam_idx], tok_idx.unsqueeze(1)], dim=1)
-            done = (tok_idx == eos) & (i > min_length)  # never true while max_length <= min_length (the reference's defaults)
-            if bool(done.any()):
-                for j in torch.nonzero(done).flatten().tolist():
-                    final_tokens.append(grown[j])
-                    final_scores.append(cand[j])
-                    count -= 1
-                grown, cand = grown[~done], cand[~done]
+            parent = beam_idx
+            if i > min_length:  # never while max_length <= min_length (the reference's defaults): no host sync per step then
+                done = tok_idx == eos
+                if bool(done.any()):
+                    for j in torch.nonzero(done).flatten().tolist():
+                        final_tokens.append(grown[j])
+                        final_scores.append(cand[j])
+                        count -= 1
+                    grown, cand, parent = grown[~done], cand[~done], beam_idx[~done]
             scores = cand
             if len(final_scores) == beam:
                 break

@@ -1,0 +1,471 @@
+// Step-wise AED decoding with a key / value cache behind the C ABI (include/eec.h, eec_decoder_begin / eec_decoder_step).
+// The reference's beam search (util/beam_infer.py:233-240) calls `_decoder_` on the whole prefix at every step: O(S^2)
+// decoder work per utterance and, at 10 beams, launches that each cover a handful of rows.  Here one step computes ONLY the new
+// position of every beam: the self-attention keys / values of earlier positions come from a cache indexed through the beams'
+// ancestry (a beam re-ordering copies 4-byte slot numbers, not keys), the memory keys / values of the utterance are projected
+// once per (utterance, exit) in eec_decoder_begin.  Same arithmetic as models/model/early_exit.py:739-762 in eval mode
+// (norm_first nn.TransformerDecoderLayer, causal + target-padding key mask, shared final LayerNorm, exit Linear, log_softmax);
+// plain fp32 FMA, fp32 weights straight from the module's parameters.
+//
+// A step has at most kRows = 16 live beams.  8 launches per decoder layer:
+//   skinny_linear (LN1 -> in_proj)  step_attn<self>  skinny_linear (out_proj, += x)
+//   skinny_linear (LN2 -> q)        step_attn<cross> skinny_linear (out_proj, += x)
+//   skinny_linear (LN3 -> linear1 -> ReLU)           skinny_linear (linear2, += x)
+#include <algorithm>
+#include <string>
+
+#include "../../include/eec.h"
+#include "eec_train.h"
+
+namespace eec {
+hipError_t ensure_max_lds(const void* kernel, int bytes);  // pack.hip
+}
+
+using namespace eect;
+
+namespace {
+
+constexpr int kRows = 16;  // live beams per step (rows of every activation of a step)
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Y[r][n] (+)= act( LN?(X[r]) . W[n] + bias[n] ), r < R <= 16.  Threads are (column c = tid / KL, k-lane j = tid % KL):
+// a workgroup owns 256 / KL output columns (KL = 16: 16 columns, for wide outputs; KL = 64: a column per wave, so that a
+// narrow output still spreads over >= 64 workgroups); the (normalised) rows sit in LDS; every weight is read once, as
+// float4, in batches of kBatch loads that are all in flight before the first one is used -- the first batch is requested
+// before the rows are staged.  The kernel is a latency chain (launch, rows, weights, reduce), not a bandwidth problem:
+// 16 x 2048 fp32 rows and a 2 MB weight matrix per call at most.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SkinnyArgs {
+  const float* X;
+  long ldx;
+  const float *ln_g, *ln_b;  // LayerNorm over K <= 1024 (eps 1e-5) in the prologue, or null
+  const float *W, *bias;     // [N][K], [N]
+  float* Y;
+  long ldy;
+  int R, N, K, relu, accumulate;
+};
+
+#define EECS_DPP_ADD(v, ctrl, rmask) \
+  ((v) + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), ctrl, rmask, 0xf, false)))
+// sum over the 16 lanes of a DPP row, left in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v = EECS_DPP_ADD(v, 0xB1, 0xf);   // quad_perm [1,0,3,2]
+  v = EECS_DPP_ADD(v, 0x4E, 0xf);   // quad_perm [2,3,0,1]
+  v = EECS_DPP_ADD(v, 0x141, 0xf);  // row_half_mirror
+  v = EECS_DPP_ADD(v, 0x140, 0xf);  // row_mirror
+  return v;
+}
+// sum over the wave, wave-uniform
+__device__ __forceinline__ float wave64_sum(float v) {
+  v = row16_sum(v);
+  v = EECS_DPP_ADD(v, 0x142, 0xa);  // row_bcast15 -> rows 1, 3
+  v = EECS_DPP_ADD(v, 0x143, 0xc);  // row_bcast31 -> rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+constexpr int kBatch = 8;
+
+// The kernel runs ONCE per workgroup, so its instruction stream is fetched cold: code size is latency.  Hence rolled loops
+// (the unrolled first version was 22 KB of straight-line code and took 9 us per call whatever the shape).
+template <int KL>
+__global__ __launch_bounds__(256) void skinny_linear_kernel(SkinnyArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs[];  // [kRows + 2][K]: the rows, then LayerNorm gain and bias
+  const int tid = threadIdx.x, K = a.K, per_row = K >> 2;
+  const int c = tid / KL, j = tid % KL, n = blockIdx.x * (256 / KL) + c;
+  const bool col = n < a.N;
+  const float* wr = a.W + (long)(col ? n : 0) * K;
+  float4 wv[kBatch];
+  auto fetch = [&](int kb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < kBatch; ++i) {
+      const int k = kb + (i * KL + j) * 4;
+      wv[i] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  fetch(0);
+  // each output (r = j, n) has one writer: its bias and, when accumulating, its old value are requested up front
+  const bool writer = col && j < a.R;
+  float* yp = a.Y + (writer ? j : 0) * a.ldy + (col ? n : 0);
+  const float bias = (writer && a.bias) ? a.bias[n] : 0.0f;
+  const float yold = (writer && a.accumulate) ? *yp : 0.0f;
+  // ---- live rows (and the LayerNorm parameters) -> LDS ----
+  float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
+  const bool ln = a.ln_g != nullptr, ln_lane = ln && tid < per_row;  // K <= 1024: one float4 of gain / bias per thread
+  if (ln_lane) g4 = reinterpret_cast<const float4*>(a.ln_g)[tid], b4 = reinterpret_cast<const float4*>(a.ln_b)[tid];
+  {
+    int r = tid / per_row, k4 = tid - r * per_row;
+    const int dr = 256 / per_row, dk = 256 - dr * per_row;  // 256 float4 further on
+    while (r < a.R) {
+      float4 t[4];
+      int at[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        at[i] = -1;
+        if (r < a.R) {
+          at[i] = r * per_row + k4;
+          t[i] = *reinterpret_cast<const float4*>(a.X + r * a.ldx + 4 * k4);
+        }
+        k4 += dk, r += dr;
+        if (k4 >= per_row) k4 -= per_row, ++r;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (at[i] >= 0) reinterpret_cast<float4*>(xs)[at[i]] = t[i];
+    }
+  }
+  if (ln_lane) {
+    reinterpret_cast<float4*>(xs)[kRows * per_row + tid] = g4;
+    reinterpret_cast<float4*>(xs)[(kRows + 1) * per_row + tid] = b4;
+  }
+  __syncthreads();
+  if (ln) {  // in place, a row per 16-lane DPP row
+    const int r = tid >> 4, l16 = tid & 15;
+    if (r < a.R) {
+      float4* xr = reinterpret_cast<float4*>(xs) + r * per_row;
+      const float4* gs = reinterpret_cast<const float4*>(xs) + kRows * per_row;
+      const float4* bs = gs + per_row;
+      float sum = 0.0f;
+      for (int q = l16; q < per_row; q += 16) {
+        const float4 v = xr[q];
+        sum += (v.x + v.y) + (v.z + v.w);
+      }
+      const float mu = row16_sum(sum) / K;
+      float sq = 0.0f;
+      for (int q = l16; q < per_row; q += 16) {
+        const float4 v = xr[q];
+        const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+        sq += dx * dx + dy * dy + dz * dz + dw * dw;
+      }
+      const float rs = rsqrtf(row16_sum(sq) / K + 1e-5f);
+      for (int q = l16; q < per_row; q += 16) {
+        float4 v = xr[q];
+        const float4 g = gs[q], b = bs[q];
+        v.x = (v.x - mu) * rs * g.x + b.x, v.y = (v.y - mu) * rs * g.y + b.y;
+        v.z = (v.z - mu) * rs * g.z + b.z, v.w = (v.w - mu) * rs * g.w + b.w;
+        xr[q] = v;
+      }
+    }
+    __syncthreads();
+  }
+  float acc[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) acc[r] = 0.0f;
+  for (int kb = 0; kb < K; kb += kBatch * KL * 4) {
+    if (kb) fetch(kb);
+#pragma unroll 1
+    for (int i = 0; i < kBatch; ++i) {
+      const int ku = kb + i * KL * 4;
+      if (ku >= K) break;
+      const float4 w0 = wv[0];
+#pragma unroll
+      for (int q = 0; q + 1 < kBatch; ++q) wv[q] = wv[q + 1];  // rotate: the loop stays rolled, the batch stays in registers
+      const float4* xk = reinterpret_cast<const float4*>(xs + ku + j * 4);
+      if (ku + j * 4 < K) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          if (r < a.R) {  // uniform
+            const float4 xv = xk[r * per_row];
+            acc[r] += w0.x * xv.x + w0.y * xv.y + w0.z * xv.z + w0.w * xv.w;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) acc[r] = KL == 16 ? row16_sum(acc[r]) : wave64_sum(acc[r]);
+  if (!writer) return;
+  float v = 0.0f;
+#pragma unroll
+  for (int r = 0; r < kRows; ++r)
+    if (j == r) v = acc[r];
+  v += bias;
+  if (a.relu) v = fmaxf(v, 0.0f);
+  *yp = yold + v;
+}
+
+hipError_t skinny_linear(const SkinnyArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)(kRows + 2) * a.K * sizeof(float);
+  if (a.N < 1024) {  // a column per wave: N / 4 workgroups
+    if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<64>, (int)lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(skinny_linear_kernel<64>, dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+  } else {
+    if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<16>, (int)lds); e != hipSuccess) return e;
+    hipLaunchKernelGGL(skinny_linear_kernel<16>, dim3((a.N + 15) / 16), dim3(256), lds, st, a);
+  }
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// New position s of every live beam: x[r] = emb[token[r]] + pe[s]; pad flag of (s, r); ancestry of beam r = ancestry of
+// its parent in the previous step + its own slot r at position s.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void step_embed_kernel(const long long* __restrict__ tok, const long long* __restrict__ parent,
+                                                         const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ x,
+                                                         unsigned char* __restrict__ pad, const int* __restrict__ anc_old, int* __restrict__ anc_new,
+                                                         int s, int S_max, int D, int V, int pad_idx, int R_prev) {
+  const int r = blockIdx.x;
+  const long long t = tok[r];
+  const long long tc = t < 0 ? 0 : (t >= V ? V - 1 : t);  // nn.Embedding would raise; stay in bounds
+  for (int c = threadIdx.x; c < D; c += 256) x[(long)r * D + c] = emb[tc * D + c] + pe[(long)s * D + c];
+  if (threadIdx.x == 0) pad[s * kRows + r] = t == pad_idx;
+  int p = 0;
+  if (s > 0) {
+    const long long pp = parent ? parent[r] : r;
+    p = (int)(pp < 0 ? 0 : (pp >= R_prev ? R_prev - 1 : pp));
+  }
+  for (int i = threadIdx.x; i <= s; i += 256) anc_new[r * S_max + i] = i < s ? anc_old[p * S_max + i] : r;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One query row per (beam r, head h) workgroup of 4 waves: softmax(q . K^T * scale) . V over the cached keys.
+// SELF: keys 0 .. s of the beam's ancestry (position s itself comes from the step's in_proj output and is appended to the
+// cache here), keys whose token is the padding index masked.  Cross: the Tk memory keys, no mask.
+// ---------------------------------------------------------------------------------------------------------------------
+struct StepAttnArgs {
+  const float* q;  // row r, head h at q + r * ldq + h * dh
+  long ldq;
+  const float *kn, *vn;  // SELF: this step's key / value rows (same row stride ldq)
+  float* kv;             // SELF: cache [S_max][kRows][2D] of the layer; cross: memory [Tk][2D]
+  const int* anc;        // [kRows][S_max]
+  const unsigned char* pad;
+  float* ctx;  // [R][D]
+  int s, S_max, Tk, D, dh;
+  float scale;
+};
+
+template <bool SELF>
+__global__ __launch_bounds__(256) void step_attn_kernel(StepAttnArgs a) {
+  extern __shared__ float lds[];
+  __shared__ float red[4][64];
+  __shared__ float stat[2][4];
+  const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int dh = a.dh, D = a.D, nk = SELF ? a.s + 1 : a.Tk;
+  float* sc = lds;                  // [nk] scores, then probabilities
+  int* slot = (int*)(lds + nk);     // [nk] SELF: cache slot of key t
+  const float* q = a.q + r * a.ldq + h * dh;
+  if (SELF && tid < dh) {  // append the new position: cache row (s, r)
+    float* dst = a.kv + ((long)a.s * kRows + r) * 2 * D + h * dh;
+    dst[tid] = a.kn[r * a.ldq + h * dh + tid];
+    dst[D + tid] = a.vn[r * a.ldq + h * dh + tid];
+  }
+  float mx = -INFINITY;
+  for (int t = tid; t < nk; t += 256) {
+    const float* kp;
+    bool live = true;
+    if (SELF) {
+      const int sl = t == a.s ? r : a.anc[r * a.S_max + t];
+      slot[t] = sl;
+      live = !a.pad[t * kRows + sl];
+      kp = t == a.s ? a.kn + r * a.ldq + h * dh : a.kv + ((long)t * kRows + sl) * 2 * D + h * dh;
+    } else {
+      kp = a.kv + (long)t * 2 * D + h * dh;
+    }
+    float d = 0.0f;
+    for (int i = 0; i < dh; i += 4) {
+      const float4 kv4 = *reinterpret_cast<const float4*>(kp + i);
+      const float4 qv = *reinterpret_cast<const float4*>(q + i);
+      d += qv.x * kv4.x + qv.y * kv4.y + qv.z * kv4.z + qv.w * kv4.w;
+    }
+    d = live ? d * a.scale : -INFINITY;
+    sc[t] = d;
+    mx = fmaxf(mx, d);
+  }
+  mx = wmax(mx);
+  if (lane == 0) stat[0][w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(stat[0][0], stat[0][1]), fmaxf(stat[0][2], stat[0][3]));
+  float sum = 0.0f;
+  for (int t = tid; t < nk; t += 256) {
+    const float p = sc[t] == -INFINITY ? 0.0f : __expf(sc[t] - mx);
+    sc[t] = p;
+    sum += p;
+  }
+  sum = wsum(sum);
+  if (lane == 0) stat[1][w] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (stat[1][0] + stat[1][1] + stat[1][2] + stat[1][3]);  // no live key: nan, as torch
+  // probabilities . V: lane = (feature d, part): the 4 * (64 / dh) (wave, part) pairs interleave the keys
+  const int parts = 64 / dh, d = lane % dh, part = lane / dh, stride = 4 * parts;
+  float acc = 0.0f;
+  for (int t0 = w * parts + part; t0 < nk; t0 += 8 * stride) {  // 8 value rows in flight per lane
+    float pv[8], vv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int t = t0 + i * stride;
+      pv[i] = 0.0f, vv[i] = 0.0f;
+      if (t < nk) {
+        const float* vp;
+        if (SELF) vp = t == a.s ? a.vn + r * a.ldq + h * dh : a.kv + ((long)t * kRows + slot[t]) * 2 * D + D + h * dh;
+        else vp = a.kv + (long)t * 2 * D + D + h * dh;
+        pv[i] = sc[t], vv[i] = vp[d];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += pv[i] * vv[i];
+  }
+  for (int m = dh; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+  red[w][lane] = acc;
+  __syncthreads();
+  if (tid < dh) a.ctx[(long)r * D + h * dh + tid] = (red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]) * inv;
+}
+
+template <bool SELF>
+hipError_t step_attn(const StepAttnArgs& a, int R, int H, hipStream_t st) {
+  const int nk = SELF ? a.s + 1 : a.Tk;
+  const size_t lds = (size_t)nk * 8;
+  if (hipError_t e = eec::ensure_max_lds((const void*)step_attn_kernel<SELF>, (int)lds); e != hipSuccess) return e;
+  hipLaunchKernelGGL(step_attn_kernel<SELF>, dim3(R, H), dim3(256), lds, st, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+thread_local std::string g_serr;
+int sfail(int code, const std::string& msg) {
+  g_serr = msg;
+  return code;
+}
+
+struct Geo {
+  int D, H, F, V, L, S_max, Tq;
+};
+struct Cache {
+  float *mem, *kv, *x, *qkv, *q, *ctx, *h, *logits;
+  int* anc;
+  unsigned char* pad;
+  size_t bytes;
+};
+Cache carve(char* base, const Geo& g) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    off = (off + 255) / 256 * 256;
+    char* p = base + off;
+    off += bytes;
+    return p;
+  };
+  Cache c{};
+  const size_t f = sizeof(float);
+  c.mem = (float*)take((size_t)g.L * g.Tq * 2 * g.D * f);
+  c.kv = (float*)take((size_t)g.L * g.S_max * kRows * 2 * g.D * f);
+  c.x = (float*)take((size_t)kRows * g.D * f);
+  c.qkv = (float*)take((size_t)kRows * 3 * g.D * f);
+  c.q = (float*)take((size_t)kRows * g.D * f);
+  c.ctx = (float*)take((size_t)kRows * g.D * f);
+  c.h = (float*)take((size_t)kRows * g.F * f);
+  c.logits = (float*)take((size_t)kRows * g.V * f);
+  c.anc = (int*)take((size_t)2 * kRows * g.S_max * sizeof(int));
+  c.pad = (unsigned char*)take((size_t)g.S_max * kRows);
+  c.bytes = off + 256;
+  return c;
+}
+
+bool geometry_ok(int d_model, int n_heads, int d_ff, int vocab, int n_layers, int S_max, int Tq) {
+  if (d_model <= 0 || n_heads <= 0 || d_model % n_heads || d_ff <= 0 || vocab <= 0 || n_layers <= 0 || S_max <= 0 || Tq <= 0) return false;
+  const int dh = d_model / n_heads;
+  if (dh != 8 && dh != 16 && dh != 32 && dh != 64) return false;  // a head's features on a power-of-two fraction of a wave
+  if (d_model % 4 || d_ff % 4) return false;                        // float4 weight rows
+  if (d_model > 1024 || d_ff > 2048) return false;                  // LayerNorm rows in registers; 16 rows of d_ff in LDS (128 KB)
+  if ((size_t)std::max(S_max, Tq) * 8 > 60000) return false;        // scores + slots of one query row in LDS
+  return true;
+}
+
+#define SRUN(expr)                                                                          \
+  do {                                                                                      \
+    hipError_t _e = (expr);                                                                 \
+    if (_e != hipSuccess) return sfail((int)_e, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* eec_decoder_step_last_error(void) { return g_serr.c_str(); }
+
+int eec_decoder_step_max_beams(void) { return kRows; }
+
+size_t eec_decoder_cache_bytes(int d_model, int n_heads, int d_ff, int vocab, int n_layers, int S_max, int Tq) {
+  if (!geometry_ok(d_model, n_heads, d_ff, vocab, n_layers, S_max, Tq)) return 0;
+  return carve(nullptr, Geo{d_model, n_heads, d_ff, vocab, n_layers, S_max, Tq}).bytes;
+}
+
+int eec_decoder_begin(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, const float* enc, int Tq, int S_max,
+                      int passes, void* cache, size_t cache_bytes, void* stream) {
+  if (!p || !p->layers || !enc || !cache) return sfail(EEC_ERR_BAD_ARG, "null argument");
+  if (passes != 1 && passes != 3) return sfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
+  if (!geometry_ok(d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq) || S_max > p->max_len)
+    return sfail(EEC_ERR_UNSUPPORTED, "geometry not served by the step-wise decoder (use eec_decoder_forward)");
+  const Geo g{d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq};
+  const Cache c = carve((char*)cache, g);
+  if (c.bytes > cache_bytes) return sfail(EEC_ERR_WORKSPACE, "cache too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = d_model;
+  for (int l = 0; l < p->n_layers; ++l) {  // memory keys | values of every layer: enc . W[D:3D]^T + b[D:3D]
+    const eec_decoder_layer_params& L = p->layers[l];
+    GemmArgs a = gemm_args(enc, D, 1, L.ca_in_w + (size_t)D * D, D, 1, c.mem + (size_t)l * Tq * 2 * D, 2 * D, Tq, 2 * D, D);
+    a.bias = L.ca_in_b + D;
+    SRUN(launch_gemm(a, passes, st));
+  }
+  return 0;
+}
+
+int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* last_tokens,
+                     const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax, float* out, void* cache,
+                     size_t cache_bytes, void* stream) {
+  if (!p || !p->layers || !last_tokens || !out || !cache) return sfail(EEC_ERR_BAD_ARG, "null argument");
+  if (!geometry_ok(d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq) || S_max > p->max_len)
+    return sfail(EEC_ERR_UNSUPPORTED, "geometry not served by the step-wise decoder (use eec_decoder_forward)");
+  if (R <= 0 || R > kRows) return sfail(EEC_ERR_BAD_ARG, "1 .. 16 live beams per step");
+  if (s < 0 || s >= S_max) return sfail(EEC_ERR_BAD_ARG, "step index outside the cache (S_max)");
+  if (s > 0 && (R_prev <= 0 || R_prev > kRows)) return sfail(EEC_ERR_BAD_ARG, "R_prev: the previous step's beam count");
+  const Geo g{d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq};
+  const Cache c = carve((char*)cache, g);
+  if (c.bytes > cache_bytes) return sfail(EEC_ERR_WORKSPACE, "cache too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = d_model, H = n_heads, dh = D / H, F = d_ff;
+  const float scale = 1.0f / sqrtf((float)dh);
+  int* anc_new = c.anc + (size_t)(s & 1) * kRows * S_max;
+  const int* anc_old = c.anc + (size_t)((s + 1) & 1) * kRows * S_max;
+  hipLaunchKernelGGL(step_embed_kernel, dim3(R), dim3(256), 0, st, (const long long*)last_tokens, (const long long*)parent, p->emb, p->pe, c.x,
+                     c.pad, anc_old, anc_new, s, S_max, D, vocab, pad_idx, R_prev);
+  SRUN(hipGetLastError());
+  auto linear = [&](const float* X, long ldx, const float* g_, const float* b_, const float* W, const float* bias, float* Y, long ldy, int N, int K,
+                    int relu, int accumulate) {
+    SkinnyArgs a{X, ldx, g_, b_, W, bias, Y, ldy, R, N, K, relu, accumulate};
+    return skinny_linear(a, st);
+  };
+  for (int l = 0; l < p->n_layers; ++l) {
+    const eec_decoder_layer_params& L = p->layers[l];
+    // self-attention over the beam's own prefix
+    SRUN(linear(c.x, D, L.norm1_w, L.norm1_b, L.sa_in_w, L.sa_in_b, c.qkv, 3 * D, 3 * D, D, 0, 0));
+    StepAttnArgs sa{c.qkv, 3L * D, c.qkv + D, c.qkv + 2 * D, c.kv + (size_t)l * S_max * kRows * 2 * D, anc_new, c.pad, c.ctx, s, S_max, 0, D, dh, scale};
+    SRUN(step_attn<true>(sa, R, H, st));
+    SRUN(linear(c.ctx, D, nullptr, nullptr, L.sa_out_w, L.sa_out_b, c.x, D, D, D, 0, 1));
+    // cross-attention over the utterance's memory
+    SRUN(linear(c.x, D, L.norm2_w, L.norm2_b, L.ca_in_w, L.ca_in_b, c.q, D, D, D, 0, 0));
+    StepAttnArgs ca{c.q, (long)D, nullptr, nullptr, c.mem + (size_t)l * Tq * 2 * D, nullptr, nullptr, c.ctx, s, S_max, Tq, D, dh, scale};
+    SRUN(step_attn<false>(ca, R, H, st));
+    SRUN(linear(c.ctx, D, nullptr, nullptr, L.ca_out_w, L.ca_out_b, c.x, D, D, D, 0, 1));
+    // feed-forward, ReLU
+    SRUN(linear(c.x, D, L.norm3_w, L.norm3_b, L.w1, L.b1, c.h, F, F, D, 1, 0));
+    SRUN(linear(c.h, F, nullptr, nullptr, L.w2, L.b2, c.x, D, D, F, 0, 1));
+  }
+  if (log_softmax) {
+    SRUN(linear(c.x, D, p->norm_w, p->norm_b, p->head_w, p->head_b, c.logits, vocab, vocab, D, 0, 0));
+    SRUN(launch_logsoftmax_fwd(c.logits, out, R, vocab, st));
+  } else {
+    SRUN(linear(c.x, D, p->norm_w, p->norm_b, p->head_w, p->head_b, out, vocab, vocab, D, 0, 0));
+  }
+  return 0;
+}
+
+}  // extern "C"

@@ -779,6 +779,60 @@ class _EncoderTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])
 
 
+class DecoderSession:
+    """One utterance's step-wise AED decoding state (include/eec.h, eec_decoder_begin / eec_decoder_step): ``step(tokens,
+    parent)`` returns the log-probs of the NEXT token for every live beam, [R, V] -- what
+    ``model._decoder_(prefixes, enc, layer_n)[:, -1]`` returns (util/beam_infer.py:236-240) -- from the last token of every
+    beam and the row of the previous step it extends."""
+
+    def __init__(self, model, ps, d_ff: int, V: int, enc: Tensor, max_steps: int, nbytes: int):
+        lib = capi.load()
+        self.model, self.ps, self.d_ff, self.V, self.max_steps, self.nbytes = model, ps, d_ff, V, max_steps, nbytes
+        self.dev, self.Tq = enc.device, enc.size(0)
+        self.s, self.rows = 0, 0
+        self.max_beams = lib.eec_decoder_step_max_beams()
+        cfg = model._cfg
+        with torch.cuda.device(self.dev):
+            self.cache = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.dev)
+            self.ptr = (self.cache.data_ptr() + 255) // 256 * 256
+            enc_c = enc.contiguous().float()
+            stream = torch.cuda.current_stream(self.dev)
+            rc = lib.eec_decoder_begin(C.byref(ps), cfg.d_model, cfg.n_heads, d_ff, V, enc_c.data_ptr(), self.Tq, max_steps,
+                                       int(model.decoder_passes), self.ptr, nbytes, C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_begin failed (code {rc}): {lib.eec_decoder_step_last_error().decode(errors='replace')}")
+            enc_c.record_stream(stream)
+            self.cache.record_stream(stream)
+
+    def step(self, last_tokens: Tensor, parent: Optional[Tensor] = None, log_softmax: bool = True) -> Tensor:
+        lib = capi.load()
+        cfg = self.model._cfg
+        R = int(last_tokens.numel())
+        if not 1 <= R <= self.max_beams:
+            raise ValueError(f"1 .. {self.max_beams} live beams per step, got {R}")
+        if self.s >= self.max_steps:
+            raise RuntimeError(f"the session was opened for {self.max_steps} steps")
+        if parent is not None and parent.numel() != R:
+            raise ValueError("parent: one row of the previous step per live beam")
+        with torch.cuda.device(self.dev):
+            tok = last_tokens.to(device=self.dev, dtype=torch.int64).contiguous()
+            par = parent.to(device=self.dev, dtype=torch.int64).contiguous() if parent is not None and self.s > 0 else None
+            out = torch.empty((R, self.V), dtype=torch.float32, device=self.dev)
+            stream = torch.cuda.current_stream(self.dev)
+            rc = lib.eec_decoder_step(C.byref(self.ps), cfg.d_model, cfg.n_heads, self.d_ff, self.V, int(self.model.trg_pad_idx),
+                                      tok.data_ptr(), par.data_ptr() if par is not None else None, R, self.rows, self.s, self.Tq,
+                                      self.max_steps, int(log_softmax), out.data_ptr(), self.ptr, self.nbytes,
+                                      C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_step failed (code {rc}): {lib.eec_decoder_step_last_error().decode(errors='replace')}")
+            tok.record_stream(stream)
+            if par is not None:
+                par.record_stream(stream)
+        self.s += 1
+        self.rows = R
+        return out
+
+
 class full_conformer(_HipEncoderMixin, nn.Module):
     """AED model: HIP encoder + the attention decoder.  Inference (``_decoder_``, ``forward`` without autograd) runs the
     decoder on the hand-written path too (csrc/decoder.hip); with autograd the decoder is the reference's
@@ -833,16 +887,9 @@ class full_conformer(_HipEncoderMixin, nn.Module):
         out = self.linears_2[idx](self.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=pad_mask))
         return torch.log_softmax(out, dim=2) if log_softmax else out
 
-    def _hip_decoder(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool) -> Tensor:
-        """``linears_2[idx](decoders[idx](positional_encoder_2(emb(trg)), enc, causal + padding masks))`` in eval semantics
-        through eec_decoder_forward; trg int64 [Bm, S], enc fp32 [Bm, T', D] -> [Bm, S, V] logits or log-probs."""
-        lib = capi.load()
-        dev = trg.device
-        cfg = self._cfg
-        Bm, S = trg.shape
-        Tq = enc.size(1)
-        if enc.size(0) != Bm or enc.size(2) != cfg.d_model:
-            raise ValueError(f"enc must be [{Bm}, T', {cfg.d_model}], got {tuple(enc.shape)}")
+    def _decoder_params(self, idx: int, dev):
+        """The C-ABI view (eec_decoder_params) of exit ``idx``'s decoder: pointers into the module's own parameters, rebuilt
+        when any of them moved."""
         dec = self.decoders[idx]
         tensors = [self.emb.weight, self.positional_encoder_2.pe, self.layer_norm.weight, self.layer_norm.bias,
                    self.linears_2[idx].weight, self.linears_2[idx].bias] + list(dec.layers.parameters())
@@ -864,9 +911,19 @@ class full_conformer(_HipEncoderMixin, nn.Module):
                                        self.linears_2[idx].bias.data_ptr())
             ent = (key, ps, layers)
             cache[idx] = ent
-        ps = ent[1]
-        layer0 = dec.layers[0]
-        d_ff, V = layer0.linear1.out_features, self.linears_2[idx].out_features
+        return ent[1], dec.layers[0].linear1.out_features, self.linears_2[idx].out_features
+
+    def _hip_decoder(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool) -> Tensor:
+        """``linears_2[idx](decoders[idx](positional_encoder_2(emb(trg)), enc, causal + padding masks))`` in eval semantics
+        through eec_decoder_forward; trg int64 [Bm, S], enc fp32 [Bm, T', D] -> [Bm, S, V] logits or log-probs."""
+        lib = capi.load()
+        dev = trg.device
+        cfg = self._cfg
+        Bm, S = trg.shape
+        Tq = enc.size(1)
+        if enc.size(0) != Bm or enc.size(2) != cfg.d_model:
+            raise ValueError(f"enc must be [{Bm}, T', {cfg.d_model}], got {tuple(enc.shape)}")
+        ps, d_ff, V = self._decoder_params(idx, dev)
         with torch.cuda.device(dev):
             trg_c = trg.to(torch.int64).contiguous()
             shared = Bm > 1 and enc.stride(0) == 0  # beam search: one utterance expanded over the beams (util/beam_infer.py:233)
@@ -884,6 +941,24 @@ class full_conformer(_HipEncoderMixin, nn.Module):
             for t in (ws, trg_c, enc_c):
                 t.record_stream(torch.cuda.current_stream(dev))
         return out
+
+    def decoder_session(self, enc: Tensor, layer_n: int, max_steps: int) -> Optional["DecoderSession"]:
+        """Step-wise decoding of ONE utterance with a key / value cache (csrc/decoder_step.hip): ``enc`` [1, T', D] or
+        [T', D] is exit ``layer_n``'s encoder output, ``max_steps`` the longest prefix that will be decoded.  None when this
+        geometry or device is not served (callers then use ``_decoder_`` on the whole prefix, as the reference does)."""
+        if not enc.is_cuda or (self.training and torch.is_grad_enabled()):
+            return None
+        idx = (int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits) - 1
+        enc2 = enc.reshape(-1, enc.size(-1)) if enc.dim() == 2 or enc.size(0) == 1 else None
+        if enc2 is None or max_steps < 1 or max_steps > self.positional_encoder_2.pe.size(0):
+            return None
+        ps, d_ff, V = self._decoder_params(idx, enc.device)
+        lib = capi.load()
+        cfg = self._cfg
+        nbytes = lib.eec_decoder_cache_bytes(cfg.d_model, cfg.n_heads, d_ff, V, len(self.decoders[idx].layers), int(max_steps), enc2.size(0))
+        if nbytes == 0:
+            return None
+        return DecoderSession(self, ps, d_ff, V, enc2, int(max_steps), nbytes)
 
     def _decoder_(self, trg: Tensor, enc: Tensor, layer_n: int) -> Tensor:
         idx = (int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits) - 1

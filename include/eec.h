@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 14
+#define EEC_ABI_VERSION 15
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -309,6 +309,29 @@ size_t eec_decoder_workspace_bytes(int d_model, int n_heads, int d_ff, int vocab
 int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* trg,
                         const float* enc, int Bm, int S, int Tq, int enc_shared, int passes, int log_softmax, float* out,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+
+/* ---- Step-wise AED decoding with a key / value cache (csrc/decoder_step.hip) ----------------------------------------------------
+ * What util/beam_infer.py:233-240 needs from `_decoder_` is the LAST position's log-probs of every live beam; the reference gets
+ * them by re-running the decoder over the whole prefix at every step.  A session here is a caller-owned device buffer `cache`
+ * (eec_decoder_cache_bytes) holding the memory keys / values of ONE utterance's encoder output (projected once by
+ * eec_decoder_begin), the self-attention keys / values of every (position, beam slot) decoded so far and each beam's ancestry.
+ *   eec_decoder_begin(p, ..., enc [Tq][D], Tq, S_max, passes, cache, bytes, stream)
+ *   eec_decoder_step (p, ..., pad_idx, last_tokens [R], parent [R] | NULL, R, R_prev, s, Tq, S_max, log_softmax, out [R][V], ...)
+ * step s = 0, 1, 2, ... in order (s < S_max <= p->max_len): last_tokens[r] is beam r's token at position s, parent[r] the row of the
+ * PREVIOUS step that beam r extends (NULL: r itself; ignored at s = 0), R_prev that step's beam count; 1 <= R <=
+ * eec_decoder_step_max_beams() (16).  out[r] = log_softmax (or the raw logits) of the exit head at position s -- what
+ * `_decoder_(prefix_r, enc, exit)[:, -1]` returns.  Plain fp32 arithmetic; the memory projection of _begin runs on the training
+ * GEMM (`passes` as eec_decoder_forward).  EEC_ERR_UNSUPPORTED for geometries outside head dim 8 / 16 / 32 / 64, d_model <= 1024
+ * and d_ff <= 2048 (multiples of 4): callers then stay on eec_decoder_forward. */
+const char* eec_decoder_step_last_error(void);
+int eec_decoder_step_max_beams(void);
+size_t eec_decoder_cache_bytes(int d_model, int n_heads, int d_ff, int vocab, int n_layers, int S_max, int Tq);
+int eec_decoder_begin(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, const float* enc, int Tq, int S_max,
+                      int passes, void* cache, size_t cache_bytes, void* stream);
+int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* last_tokens,
+                     const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax, float* out, void* cache,
+                     size_t cache_bytes, void* stream);
 
 #ifdef __cplusplus
 }

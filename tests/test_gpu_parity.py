@@ -41,7 +41,7 @@ def run_gpu(model, mel, lens, prec="f16f8"):
 def test_native_library_is_loaded():
     from early_exit_transformer_amd import capi
     lib = capi.load()
-    assert lib.eec_abi_version() == 14
+    assert lib.eec_abi_version() == 15
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
@@ -590,6 +590,96 @@ def test_hip_decoder_matches_the_reference_decoder_modules():
             # bf16x3 GEMMs are good to ~1e-5 RELATIVE: the synthetic decoder's log-probs reach -40 (measured error 2e-4 there)
             tol = 2e-5 * max(10.0, w[ok].abs().max().item())
             assert (w[ok] - gt[ok]).abs().max().item() < tol, (Bm, S, Tq, (w[ok] - gt[ok]).abs().max().item(), tol)
+
+
+@pytest.mark.parametrize("d_model,n_head,d_ff,beams", [(256, 8, 512, 10), (512, 8, 2048, 16), (64, 4, 128, 3)])
+def test_decoder_session_steps_match_the_reference_decoder_on_whole_prefixes(d_model, n_head, d_ff, beams):
+    """Step-wise decoding over the key / value cache (eec_decoder_begin / eec_decoder_step) against what the reference's beam
+    search computes at every step (util/beam_infer.py:233-240): its own decoder modules (CPU, fp32) on the WHOLE prefix of every
+    live beam, last position.  The beams are re-ordered at random each step (parents with repeats and drop-outs, a changing
+    beam count), prefixes contain PAD tokens (masked as self-attention keys); head dims 32, 64 and 16."""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=d_model, n_head=n_head, d_feed_forward=d_ff, depthwise_kernel_size=31, dec_voc_size=256)
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=2, **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, 7), strict=True)
+    g = torch.Generator().manual_seed(d_model + beams)
+    Tq, steps = 37, 14
+    enc = torch.randn(1, Tq, d_model, generator=g)
+    ref = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cpu",
+                         n_dec_layers=2, **kw).eval()
+    ref.load_state_dict(fc.state_dict())
+    fc = fc.cuda()
+    for exit_n in (1, 2):
+        sess = fc.decoder_session(enc.cuda(), exit_n, steps)
+        assert sess is not None and sess.max_beams == 16
+        prefixes = torch.tensor([[1]])
+        parent = None
+        worst = 0.0
+        for s in range(steps):
+            got = sess.step(prefixes[:, -1].cuda(), None if parent is None else parent.cuda()).cpu()
+            with torch.no_grad():
+                want = ref._decoder_(prefixes, enc.expand(prefixes.size(0), -1, -1), exit_n)[:, -1]
+            assert got.shape == want.shape
+            tol = 2e-5 * max(10.0, want.abs().max().item())
+            err = (got - want).abs().max().item()
+            assert err < tol, (exit_n, s, err, tol)
+            worst = max(worst, err / tol)
+            # next step: a random number of beams, each extending a random row of this step with a random token (PAD now and then)
+            R = beams if s % 5 != 3 else max(1, beams // 2)
+            parent = torch.randint(0, prefixes.size(0), (R,), generator=g)
+            tok = torch.randint(3, 256, (R,), generator=g)
+            tok[torch.rand(R, generator=g) < 0.15] = 126
+            prefixes = torch.cat([prefixes[parent], tok.unsqueeze(1)], dim=1)
+        with pytest.raises(RuntimeError):
+            sess.step(prefixes[:, -1].cuda(), parent.cuda())  # opened for `steps` positions
+    assert fc.decoder_session(enc.cuda().expand(2, -1, -1), 1, steps) is None  # one utterance per session
+
+
+def test_aed_beam_search_with_and_without_the_kv_cache():
+    """BeamInference.beam_search through the step-wise decoder session (default) and on whole prefixes (`kv_cache=False`,
+    the reference's way) return the same beams: identical tokens wherever the candidate scores are not within rounding of
+    each other, final scores within 1e-3."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    from early_exit_transformer_amd.beam import BeamInference
+    z = np.load(os.path.join(GOLDEN, "aed_greedy.npz"))
+    kw = eval(str(z["kwargs"]))
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=int(z["n_dec_layers"]), **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, int(z["seed"])), strict=True)
+    fc = fc.cuda()
+    inf = BeamInference()
+    g = torch.Generator().manual_seed(2)
+    same = 0
+    for case in range(3):
+        enc = torch.randn(1, 40 + 13 * case, kw["d_model"], generator=g).cuda()
+        for n in (1, kw["n_enc_exits"]):
+            args = dict(vocab_size=256, max_length=12, SOS_token=1, EOS_token=2, PAD_token=126, beam_size=10, pen_alpha=0.6)
+            ta, sa, ba = inf.beam_search(fc, enc, n, **args)
+            tb, sb, bb = inf.beam_search(fc, enc, n, kv_cache=False, **args)
+            sa_, sb_ = torch.stack(sa).cpu().sort().values, torch.stack(sb).cpu().sort().values
+            assert (sa_ - sb_).abs().max().item() < 1e-3
+            gaps = (sb_[1:] - sb_[:-1]).abs().min().item()
+            if gaps > 2e-3:  # no two candidates within rounding: the beams must be the same sequences in the same order
+                assert [t.tolist() for t in ta] == [t.tolist() for t in tb] and ba == bb
+                same += 1
+    assert same >= 3
+    # EOS finalisation (min_length below the step count) removes rows mid-search: the parent indices must follow
+    args = dict(vocab_size=256, max_length=10, min_length=2, SOS_token=1, EOS_token=2, PAD_token=126, beam_size=6, pen_alpha=0.6)
+    first = fc._decoder_(torch.tensor([[1]], device="cuda"), enc, 1)[0, -1]
+    eos = int(first.topk(3).indices[2])  # a token the head likes right after SOS: beams finish at different steps
+    args["EOS_token"] = eos
+    ta, sa, ba = inf.beam_search(fc, enc, 1, **args)
+    tb, sb, bb = inf.beam_search(fc, enc, 1, kv_cache=False, **args)
+    assert len(ta) == len(tb) == 6
+    assert (torch.stack(sa).cpu().sort().values - torch.stack(sb).cpu().sort().values).abs().max().item() < 1e-3
 
 
 def test_aed_beam_search_golden():

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
     assert set(capi.EXPORTS) == declared
-    assert lib.eec_abi_version() == 14
+    assert lib.eec_abi_version() == 15
 
 
 def test_trainer_workspace_sizing_runs_without_a_device(lib):
@@ -63,6 +63,27 @@ def test_decoder_workspace_sizing_and_argument_checks(lib):
     ps = capi.EecDecoderParams()
     rc = lib.eec_decoder_forward(C.byref(ps), 256, 8, 2048, 256, 126, None, None, 1, 1, 1, 0, 3, 1, None, None, 0, None)
     assert rc != 0 and b"null" in lib.eec_decoder_last_error()
+
+
+def test_decoder_step_cache_sizing_and_argument_checks(lib):
+    """The step-wise decoder's cache size is host arithmetic (linear in the steps and in T'); unsupported geometries size to
+    0 and the entry points reject bad arguments before touching a device."""
+    import ctypes as C
+    assert lib.eec_decoder_step_max_beams() == 16
+    n1 = lib.eec_decoder_cache_bytes(256, 8, 2048, 256, 6, 40, 256)
+    n2 = lib.eec_decoder_cache_bytes(256, 8, 2048, 256, 6, 80, 256)
+    n3 = lib.eec_decoder_cache_bytes(256, 8, 2048, 256, 6, 80, 512)
+    assert 0 < n1 < n2 < n3
+    per_step = 6 * 16 * 2 * 256 * 4  # keys | values of 16 beam slots in every layer
+    assert abs((n2 - n1) - 40 * (per_step + 2 * 16 * 4 + 16)) <= 4096
+    assert lib.eec_decoder_cache_bytes(512, 8, 2048, 256, 6, 40, 256) > n1   # head dim 64
+    assert lib.eec_decoder_cache_bytes(384, 8, 2048, 256, 6, 40, 256) == 0   # head dim 48: not a power-of-two share of a wave
+    assert lib.eec_decoder_cache_bytes(256, 8, 4096, 256, 6, 40, 256) == 0   # 16 rows of d_ff do not fit the LDS
+    ps = capi.EecDecoderParams()
+    assert lib.eec_decoder_begin(C.byref(ps), 256, 8, 2048, 256, None, 256, 40, 3, None, 0, None) != 0
+    assert b"null" in lib.eec_decoder_step_last_error()
+    rc = lib.eec_decoder_step(C.byref(ps), 256, 8, 2048, 256, 126, None, None, 1, 0, 0, 256, 40, 1, None, None, 0, None)
+    assert rc != 0 and b"null" in lib.eec_decoder_step_last_error()
 
 
 def test_out_frames_matches_conv_arithmetic(lib):
