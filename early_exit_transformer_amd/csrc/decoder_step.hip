@@ -107,20 +107,18 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkinnyArgs a) {
     int r = tid / per_row, k4 = tid - r * per_row;
     const int dr = 256 / per_row, dk = 256 - dr * per_row;  // 256 float4 further on
     while (r < a.R) {
-      float4 t[4];
-      int at[4];
+      float4 t[8];  // the rows were written by another XCD: every round trip goes to memory, so keep many in flight
+      int at[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        at[i] = -1;
-        if (r < a.R) {
-          at[i] = r * per_row + k4;
-          t[i] = *reinterpret_cast<const float4*>(a.X + r * a.ldx + 4 * k4);
-        }
+      for (int i = 0; i < 8; ++i) {
+        const bool on = r < a.R;
+        at[i] = on ? r * per_row + k4 : -1;
+        t[i] = *reinterpret_cast<const float4*>(a.X + (on ? r * a.ldx + 4 * k4 : 0));
         k4 += dk, r += dr;
         if (k4 >= per_row) k4 -= per_row, ++r;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 8; ++i)
         if (at[i] >= 0) reinterpret_cast<float4*>(xs)[at[i]] = t[i];
     }
   }
