@@ -345,8 +345,8 @@ def main():
             d_full, hyps_full = timed(kv_cache=False)  # the reference's way: the decoder re-run on the whole prefix at every step
             steps5 = int(T / 12)
             aed = {"workload": f"full_conformer (6 x 2 encoder, 6 decoder layers per exit), 1 utterance of {T} mel frames: encoder once, "
-                               f"beam search (beam 10, {steps5} steps) for each of the 6 exits, step-wise decoder over a key / value cache "
-                               "(eec_decoder_begin / eec_decoder_step)",
+                               f"beam search (beam 10, {steps5} steps) for each of the 6 exits, step-wise decoder over a key / value cache, the 6 "
+                               "searches in lockstep through the same launches (eec_decoder_begin / eec_decoder_step_multi)",
                    "seconds_per_utterance": round(d, 4), "decoder_steps": 6 * steps5, "ms_per_decoder_step": round(d / (6 * steps5) * 1e3, 3),
                    "tokens_out": [len(h) for h in hyps],
                    "whole_prefix_decoder": {"what": "same search, eec_decoder_forward on the whole prefix per step (no cache)",

@@ -135,5 +135,45 @@ class BeamInference:
             max_length = int(30 - T * 5 / 200) if T < 200 else int(T / 12)
         taps = model._run_encoder(spec.unsqueeze(0), valid_len.reshape(1), want_out=False, want_taps=True,
                                   n_groups=model._cfg.n_exits)[1]
-        return [self.beam_search(model, taps[n - 1], n, max_length=max_length, beam_size=beam_size, **kw)[2]
-                for n in range(1, model._cfg.n_exits + 1)]
+        exits = list(range(1, model._cfg.n_exits + 1))
+        if kw.get("kv_cache", True):
+            together = self.beam_search_exits(model, [taps[n - 1] for n in exits], exits, max_length=max_length, beam_size=beam_size,
+                                              **{k: v for k, v in kw.items() if k != "kv_cache"})
+            if together is not None:
+                return [best for _, _, best in together]
+        return [self.beam_search(model, taps[n - 1], n, max_length=max_length, beam_size=beam_size, **kw)[2] for n in exits]
+
+    @torch.no_grad()
+    def beam_search_exits(self, model, encoder_outputs: Sequence[Tensor], layer_ns: Sequence[int], vocab_size: Optional[int] = None,
+                          max_length: int = 500, min_length: int = 300, SOS_token: Optional[int] = None, EOS_token: Optional[int] = None,
+                          PAD_token: Optional[int] = None, beam_size: Optional[int] = None, pen_alpha: Optional[float] = None):
+        """``beam_search`` for several exits of one utterance in lockstep: the searches are independent, so every decoder
+        launch and every bookkeeping op covers all of them (``model.decoder_session_group``).  Returns the list of
+        ``(final_tokens, final_scores, best_tokens)`` per exit, the same values as ``beam_search`` exit by exit -- or None
+        when the lockstep does not apply: no session group for this model / geometry, or EOS could finalise beams
+        (``max_length - 1 > min_length``), which would let the exits' beam counts diverge."""
+        V = self._arg(vocab_size, "dec_voc_size")
+        sos = self._arg(SOS_token, "trg_sos_idx")
+        self._arg(EOS_token, "trg_eos_idx"), self._arg(PAD_token, "trg_pad_idx")
+        beam = self._arg(beam_size, "beam_size")
+        alpha = self._arg(pen_alpha, "pen_alpha")
+        if max_length < 1 or max_length - 1 > min_length or not hasattr(model, "decoder_session_group"):
+            return None
+        if any(e.size(0) != 1 for e in encoder_outputs):
+            return None
+        group = model.decoder_session_group(encoder_outputs, layer_ns, max_length)
+        if group is None or beam > group.max_beams:
+            return None
+        n, dev = len(layer_ns), encoder_outputs[0].device
+        tokens = torch.full((n, 1, 1), sos, dtype=torch.long, device=dev)  # [exits, live beams, s]
+        scores = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        parent: Optional[Tensor] = None
+        for i in range(max_length):
+            logp = group.step(tokens[:, :, -1], parent) / sequence_length_penalty(i + 1, alpha)
+            scores, idx = torch.topk((scores.unsqueeze(2) + logp).reshape(n, -1), beam, dim=1)
+            parent = torch.div(idx, V, rounding_mode="floor")
+            tok_idx = torch.remainder(idx, V)
+            tokens = torch.cat([torch.gather(tokens, 1, parent.unsqueeze(2).expand(-1, -1, tokens.size(2))), tok_idx.unsqueeze(2)], dim=2)
+        best = scores.argmax(dim=1).tolist()
+        tokens_h = tokens.cpu()
+        return [(list(tokens[e]), list(scores[e]), tokens_h[e, best[e]].tolist()) for e in range(n)]

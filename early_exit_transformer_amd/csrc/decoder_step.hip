@@ -25,7 +25,12 @@ using namespace eect;
 
 namespace {
 
-constexpr int kRows = 16;  // live beams per step (rows of every activation of a step)
+constexpr int kRows = 16;   // live beams per step (rows of every activation of a step)
+constexpr int kGroup = 8;   // sessions (exits of one utterance) advanced by the same launches: one more grid dimension
+template <typename A>
+struct Group {
+  A a[kGroup];
+};
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -79,7 +84,8 @@ constexpr int kBatch = 8;
 // The kernel runs ONCE per workgroup, so its instruction stream is fetched cold: code size is latency.  Hence rolled loops
 // (the unrolled first version was 22 KB of straight-line code and took 9 us per call whatever the shape).
 template <int KL>
-__global__ __launch_bounds__(256) void skinny_linear_kernel(SkinnyArgs a) {
+__global__ __launch_bounds__(256) void skinny_linear_kernel(Group<SkinnyArgs> grp) {
+  const SkinnyArgs& a = grp.a[blockIdx.y];
   extern __shared__ __attribute__((aligned(16))) float xs[];  // [kRows + 2][K]: the rows, then LayerNorm gain and bias
   const int tid = threadIdx.x, K = a.K, per_row = K >> 2;
   const int c = tid / KL, j = tid % KL, n = blockIdx.x * (256 / KL) + c;
@@ -192,14 +198,16 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(SkinnyArgs a) {
   *yp = yold + v;
 }
 
-hipError_t skinny_linear(const SkinnyArgs& a, hipStream_t st) {
+// the n sessions of a group share every shape (N, K, R): only pointers differ
+hipError_t skinny_linear(const Group<SkinnyArgs>& g, int n, hipStream_t st) {
+  const SkinnyArgs& a = g.a[0];
   const size_t lds = (size_t)(kRows + 2) * a.K * sizeof(float);
   if (a.N < 1024) {  // a column per wave: N / 4 workgroups
     if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<64>, (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(skinny_linear_kernel<64>, dim3((a.N + 3) / 4), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(skinny_linear_kernel<64>, dim3((a.N + 3) / 4, n), dim3(256), lds, st, g);
   } else {
     if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<16>, (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(skinny_linear_kernel<16>, dim3((a.N + 15) / 16), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(skinny_linear_kernel<16>, dim3((a.N + 15) / 16, n), dim3(256), lds, st, g);
   }
   return hipGetLastError();
 }
@@ -208,21 +216,45 @@ hipError_t skinny_linear(const SkinnyArgs& a, hipStream_t st) {
 // New position s of every live beam: x[r] = emb[token[r]] + pe[s]; pad flag of (s, r); ancestry of beam r = ancestry of
 // its parent in the previous step + its own slot r at position s.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void step_embed_kernel(const long long* __restrict__ tok, const long long* __restrict__ parent,
-                                                         const float* __restrict__ emb, const float* __restrict__ pe, float* __restrict__ x,
-                                                         unsigned char* __restrict__ pad, const int* __restrict__ anc_old, int* __restrict__ anc_new,
-                                                         int s, int S_max, int D, int V, int pad_idx, int R_prev) {
+struct EmbedArgs {
+  const long long *tok, *parent;
+  const float *emb, *pe;
+  float* x;
+  unsigned char* pad;
+  const int* anc_old;
+  int* anc_new;
+};
+__global__ __launch_bounds__(256) void step_embed_kernel(Group<EmbedArgs> grp, int s, int S_max, int D, int V, int pad_idx, int R_prev) {
+  const EmbedArgs& a = grp.a[blockIdx.y];
   const int r = blockIdx.x;
-  const long long t = tok[r];
+  const long long t = a.tok[r];
   const long long tc = t < 0 ? 0 : (t >= V ? V - 1 : t);  // nn.Embedding would raise; stay in bounds
-  for (int c = threadIdx.x; c < D; c += 256) x[(long)r * D + c] = emb[tc * D + c] + pe[(long)s * D + c];
-  if (threadIdx.x == 0) pad[s * kRows + r] = t == pad_idx;
+  for (int c = threadIdx.x; c < D; c += 256) a.x[(long)r * D + c] = a.emb[tc * D + c] + a.pe[(long)s * D + c];
+  if (threadIdx.x == 0) a.pad[s * kRows + r] = t == pad_idx;
   int p = 0;
   if (s > 0) {
-    const long long pp = parent ? parent[r] : r;
+    const long long pp = a.parent ? a.parent[r] : r;
     p = (int)(pp < 0 ? 0 : (pp >= R_prev ? R_prev - 1 : pp));
   }
-  for (int i = threadIdx.x; i <= s; i += 256) anc_new[r * S_max + i] = i < s ? anc_old[p * S_max + i] : r;
+  for (int i = threadIdx.x; i <= s; i += 256) a.anc_new[r * S_max + i] = i < s ? a.anc_old[p * S_max + i] : r;
+}
+
+// log_softmax of the exit head's logits, a wave per (beam, session)
+struct LsmArgs {
+  const float* logits;
+  float* out;
+};
+__global__ __launch_bounds__(64) void step_logsoftmax_kernel(Group<LsmArgs> grp, int V) {
+  const LsmArgs& a = grp.a[blockIdx.y];
+  const int lane = threadIdx.x;
+  const float* xr = a.logits + (long)blockIdx.x * V;
+  float mx = -INFINITY;
+  for (int k = lane; k < V; k += 64) mx = fmaxf(mx, xr[k]);
+  mx = wmax(mx);
+  float sum = 0.0f;
+  for (int k = lane; k < V; k += 64) sum += expf(xr[k] - mx);
+  const float lse = mx + logf(wsum(sum));
+  for (int k = lane; k < V; k += 64) a.out[(long)blockIdx.x * V + k] = xr[k] - lse;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -243,7 +275,8 @@ struct StepAttnArgs {
 };
 
 template <bool SELF>
-__global__ __launch_bounds__(256) void step_attn_kernel(StepAttnArgs a) {
+__global__ __launch_bounds__(256) void step_attn_kernel(Group<StepAttnArgs> grp) {
+  const StepAttnArgs& a = grp.a[blockIdx.z];
   extern __shared__ float lds[];
   __shared__ float red[4][64];
   __shared__ float stat[2][4];
@@ -319,11 +352,11 @@ __global__ __launch_bounds__(256) void step_attn_kernel(StepAttnArgs a) {
 }
 
 template <bool SELF>
-hipError_t step_attn(const StepAttnArgs& a, int R, int H, hipStream_t st) {
-  const int nk = SELF ? a.s + 1 : a.Tk;
+hipError_t step_attn(const Group<StepAttnArgs>& g, int n, int R, int H, hipStream_t st) {
+  const int nk = SELF ? g.a[0].s + 1 : g.a[0].Tk;
   const size_t lds = (size_t)nk * 8;
   if (hipError_t e = eec::ensure_max_lds((const void*)step_attn_kernel<SELF>, (int)lds); e != hipSuccess) return e;
-  hipLaunchKernelGGL(step_attn_kernel<SELF>, dim3(R, H), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(step_attn_kernel<SELF>, dim3(R, H, n), dim3(256), lds, st, g);
   return hipGetLastError();
 }
 
@@ -416,54 +449,92 @@ int eec_decoder_begin(const eec_decoder_params* p, int d_model, int n_heads, int
   return 0;
 }
 
-int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* last_tokens,
-                     const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax, float* out, void* cache,
-                     size_t cache_bytes, void* stream) {
-  if (!p || !p->layers || !last_tokens || !out || !cache) return sfail(EEC_ERR_BAD_ARG, "null argument");
-  if (!geometry_ok(d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq) || S_max > p->max_len)
+int eec_decoder_step_multi(int n, const eec_decoder_params* const* ps, int d_model, int n_heads, int d_ff, int vocab, int pad_idx,
+                           const int64_t* last_tokens, const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax,
+                           float* out, void* const* caches, size_t cache_bytes, void* stream) {
+  if (n <= 0 || n > kGroup) return sfail(EEC_ERR_BAD_ARG, "1 .. 8 sessions per call");
+  if (!ps || !last_tokens || !out || !caches) return sfail(EEC_ERR_BAD_ARG, "null argument");
+  for (int i = 0; i < n; ++i) {
+    if (!ps[i] || !ps[i]->layers || !caches[i]) return sfail(EEC_ERR_BAD_ARG, "null argument");
+    if (ps[i]->n_layers != ps[0]->n_layers) return sfail(EEC_ERR_BAD_ARG, "the sessions of a call share one decoder geometry");
+    if (S_max > ps[i]->max_len) return sfail(EEC_ERR_UNSUPPORTED, "S_max beyond the positional-encoding table");
+  }
+  const int n_layers = ps[0]->n_layers;
+  if (!geometry_ok(d_model, n_heads, d_ff, vocab, n_layers, S_max, Tq))
     return sfail(EEC_ERR_UNSUPPORTED, "geometry not served by the step-wise decoder (use eec_decoder_forward)");
   if (R <= 0 || R > kRows) return sfail(EEC_ERR_BAD_ARG, "1 .. 16 live beams per step");
   if (s < 0 || s >= S_max) return sfail(EEC_ERR_BAD_ARG, "step index outside the cache (S_max)");
   if (s > 0 && (R_prev <= 0 || R_prev > kRows)) return sfail(EEC_ERR_BAD_ARG, "R_prev: the previous step's beam count");
-  const Geo g{d_model, n_heads, d_ff, vocab, p->n_layers, S_max, Tq};
-  const Cache c = carve((char*)cache, g);
-  if (c.bytes > cache_bytes) return sfail(EEC_ERR_WORKSPACE, "cache too small");
+  const Geo g{d_model, n_heads, d_ff, vocab, n_layers, S_max, Tq};
+  Cache c[kGroup];
+  for (int i = 0; i < n; ++i) {
+    c[i] = carve((char*)caches[i], g);
+    if (c[i].bytes > cache_bytes) return sfail(EEC_ERR_WORKSPACE, "cache too small");
+  }
   hipStream_t st = (hipStream_t)stream;
   const int D = d_model, H = n_heads, dh = D / H, F = d_ff;
   const float scale = 1.0f / sqrtf((float)dh);
-  int* anc_new = c.anc + (size_t)(s & 1) * kRows * S_max;
-  const int* anc_old = c.anc + (size_t)((s + 1) & 1) * kRows * S_max;
-  hipLaunchKernelGGL(step_embed_kernel, dim3(R), dim3(256), 0, st, (const long long*)last_tokens, (const long long*)parent, p->emb, p->pe, c.x,
-                     c.pad, anc_old, anc_new, s, S_max, D, vocab, pad_idx, R_prev);
-  SRUN(hipGetLastError());
-  auto linear = [&](const float* X, long ldx, const float* g_, const float* b_, const float* W, const float* bias, float* Y, long ldy, int N, int K,
-                    int relu, int accumulate) {
-    SkinnyArgs a{X, ldx, g_, b_, W, bias, Y, ldy, R, N, K, relu, accumulate};
-    return skinny_linear(a, st);
-  };
-  for (int l = 0; l < p->n_layers; ++l) {
-    const eec_decoder_layer_params& L = p->layers[l];
-    // self-attention over the beam's own prefix
-    SRUN(linear(c.x, D, L.norm1_w, L.norm1_b, L.sa_in_w, L.sa_in_b, c.qkv, 3 * D, 3 * D, D, 0, 0));
-    StepAttnArgs sa{c.qkv, 3L * D, c.qkv + D, c.qkv + 2 * D, c.kv + (size_t)l * S_max * kRows * 2 * D, anc_new, c.pad, c.ctx, s, S_max, 0, D, dh, scale};
-    SRUN(step_attn<true>(sa, R, H, st));
-    SRUN(linear(c.ctx, D, nullptr, nullptr, L.sa_out_w, L.sa_out_b, c.x, D, D, D, 0, 1));
-    // cross-attention over the utterance's memory
-    SRUN(linear(c.x, D, L.norm2_w, L.norm2_b, L.ca_in_w, L.ca_in_b, c.q, D, D, D, 0, 0));
-    StepAttnArgs ca{c.q, (long)D, nullptr, nullptr, c.mem + (size_t)l * Tq * 2 * D, nullptr, nullptr, c.ctx, s, S_max, Tq, D, dh, scale};
-    SRUN(step_attn<false>(ca, R, H, st));
-    SRUN(linear(c.ctx, D, nullptr, nullptr, L.ca_out_w, L.ca_out_b, c.x, D, D, D, 0, 1));
-    // feed-forward, ReLU
-    SRUN(linear(c.x, D, L.norm3_w, L.norm3_b, L.w1, L.b1, c.h, F, F, D, 1, 0));
-    SRUN(linear(c.h, F, nullptr, nullptr, L.w2, L.b2, c.x, D, D, F, 0, 1));
+  const size_t anc_new = (size_t)(s & 1) * kRows * S_max, anc_old = (size_t)((s + 1) & 1) * kRows * S_max;
+  {
+    Group<EmbedArgs> e{};
+    for (int i = 0; i < n; ++i)
+      e.a[i] = EmbedArgs{(const long long*)last_tokens + (size_t)i * R, parent ? (const long long*)parent + (size_t)i * R : nullptr, ps[i]->emb,
+                         ps[i]->pe, c[i].x, c[i].pad, c[i].anc + anc_old, c[i].anc + anc_new};
+    hipLaunchKernelGGL(step_embed_kernel, dim3(R, n), dim3(256), 0, st, e, s, S_max, D, vocab, pad_idx, R_prev);
+    SRUN(hipGetLastError());
   }
+  // one skinny_linear launch for all sessions: session i's operands through f(i)
+  auto linear = [&](auto f, int N, int K, int relu, int accumulate) {
+    Group<SkinnyArgs> grp{};
+    for (int i = 0; i < n; ++i) {
+      grp.a[i] = f(i);
+      grp.a[i].R = R, grp.a[i].N = N, grp.a[i].K = K, grp.a[i].relu = relu, grp.a[i].accumulate = accumulate;
+    }
+    return skinny_linear(grp, n, st);
+  };
+  for (int l = 0; l < n_layers; ++l) {
+    auto L = [&](int i) -> const eec_decoder_layer_params& { return ps[i]->layers[l]; };
+    // self-attention over the beam's own prefix
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, L(i).norm1_w, L(i).norm1_b, L(i).sa_in_w, L(i).sa_in_b, c[i].qkv, 3L * D}; }, 3 * D, D, 0, 0));
+    {
+      Group<StepAttnArgs> sa{};
+      for (int i = 0; i < n; ++i)
+        sa.a[i] = StepAttnArgs{c[i].qkv, 3L * D, c[i].qkv + D, c[i].qkv + 2 * D, c[i].kv + (size_t)l * S_max * kRows * 2 * D, c[i].anc + anc_new, c[i].pad,
+                               c[i].ctx, s, S_max, 0, D, dh, scale};
+      SRUN(step_attn<true>(sa, n, R, H, st));
+    }
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].ctx, D, nullptr, nullptr, L(i).sa_out_w, L(i).sa_out_b, c[i].x, D}; }, D, D, 0, 1));
+    // cross-attention over the utterance's memory
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, L(i).norm2_w, L(i).norm2_b, L(i).ca_in_w, L(i).ca_in_b, c[i].q, D}; }, D, D, 0, 0));
+    {
+      Group<StepAttnArgs> ca{};
+      for (int i = 0; i < n; ++i)
+        ca.a[i] = StepAttnArgs{c[i].q, (long)D, nullptr, nullptr, c[i].mem + (size_t)l * Tq * 2 * D, nullptr, nullptr, c[i].ctx, s, S_max, Tq, D, dh, scale};
+      SRUN(step_attn<false>(ca, n, R, H, st));
+    }
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].ctx, D, nullptr, nullptr, L(i).ca_out_w, L(i).ca_out_b, c[i].x, D}; }, D, D, 0, 1));
+    // feed-forward, ReLU
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, L(i).norm3_w, L(i).norm3_b, L(i).w1, L(i).b1, c[i].h, F}; }, F, D, 1, 0));
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].h, F, nullptr, nullptr, L(i).w2, L(i).b2, c[i].x, D}; }, D, F, 0, 1));
+  }
+  const size_t out_stride = (size_t)R * vocab;
   if (log_softmax) {
-    SRUN(linear(c.x, D, p->norm_w, p->norm_b, p->head_w, p->head_b, c.logits, vocab, vocab, D, 0, 0));
-    SRUN(launch_logsoftmax_fwd(c.logits, out, R, vocab, st));
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, ps[i]->norm_w, ps[i]->norm_b, ps[i]->head_w, ps[i]->head_b, c[i].logits, vocab}; }, vocab, D, 0, 0));
+    Group<LsmArgs> lg{};
+    for (int i = 0; i < n; ++i) lg.a[i] = LsmArgs{c[i].logits, out + i * out_stride};
+    hipLaunchKernelGGL(step_logsoftmax_kernel, dim3(R, n), dim3(64), 0, st, lg, vocab);
+    SRUN(hipGetLastError());
   } else {
-    SRUN(linear(c.x, D, p->norm_w, p->norm_b, p->head_w, p->head_b, out, vocab, vocab, D, 0, 0));
+    SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, ps[i]->norm_w, ps[i]->norm_b, ps[i]->head_w, ps[i]->head_b, out + i * out_stride, vocab}; }, vocab, D, 0, 0));
   }
   return 0;
+}
+
+int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* last_tokens,
+                     const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax, float* out, void* cache,
+                     size_t cache_bytes, void* stream) {
+  return eec_decoder_step_multi(1, &p, d_model, n_heads, d_ff, vocab, pad_idx, last_tokens, parent, R, R_prev, s, Tq, S_max, log_softmax, out, &cache,
+                                cache_bytes, stream);
 }
 
 }  // extern "C"

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 from torch import Tensor, nn
@@ -833,6 +833,59 @@ class DecoderSession:
         return out
 
 
+class DecoderSessionGroup:
+    """The step-wise decoding sessions of several exits of ONE utterance advanced in lockstep by the same launches
+    (eec_decoder_step_multi): ``step(tokens [n, R], parent [n, R])`` -> log-probs [n, R, V]."""
+
+    MAX = 8
+
+    def __init__(self, sessions: List["DecoderSession"]):
+        s0 = sessions[0]
+        if not 1 <= len(sessions) <= self.MAX:
+            raise ValueError(f"1 .. {self.MAX} sessions per group")
+        for s in sessions:
+            if (s.dev, s.Tq, s.max_steps, s.nbytes, s.V, s.d_ff, s.s) != (s0.dev, s0.Tq, s0.max_steps, s0.nbytes, s0.V, s0.d_ff, 0):
+                raise ValueError("the sessions of a group share device, geometry and step budget, and have not stepped yet")
+        self.sessions = sessions
+        n = len(sessions)
+        self.ps = (C.POINTER(capi.EecDecoderParams) * n)(*[C.pointer(s.ps) for s in sessions])
+        self.caches = (C.c_void_p * n)(*[s.ptr for s in sessions])
+        self.s, self.rows, self.max_beams = 0, 0, s0.max_beams
+
+    def step(self, last_tokens: Tensor, parent: Optional[Tensor] = None, log_softmax: bool = True) -> Tensor:
+        lib = capi.load()
+        s0 = self.sessions[0]
+        cfg = s0.model._cfg
+        n = len(self.sessions)
+        if last_tokens.dim() != 2 or last_tokens.size(0) != n:
+            raise ValueError(f"last_tokens must be [{n}, live beams]")
+        R = int(last_tokens.size(1))
+        if not 1 <= R <= self.max_beams:
+            raise ValueError(f"1 .. {self.max_beams} live beams per step, got {R}")
+        if self.s >= s0.max_steps:
+            raise RuntimeError(f"the sessions were opened for {s0.max_steps} steps")
+        if parent is not None and tuple(parent.shape) != (n, R):
+            raise ValueError("parent: one row of the previous step per live beam and session")
+        with torch.cuda.device(s0.dev):
+            tok = last_tokens.to(device=s0.dev, dtype=torch.int64).contiguous()
+            par = parent.to(device=s0.dev, dtype=torch.int64).contiguous() if parent is not None and self.s > 0 else None
+            out = torch.empty((n, R, s0.V), dtype=torch.float32, device=s0.dev)
+            stream = torch.cuda.current_stream(s0.dev)
+            rc = lib.eec_decoder_step_multi(n, self.ps, cfg.d_model, cfg.n_heads, s0.d_ff, s0.V, int(s0.model.trg_pad_idx), tok.data_ptr(),
+                                            par.data_ptr() if par is not None else None, R, self.rows, self.s, s0.Tq, s0.max_steps,
+                                            int(log_softmax), out.data_ptr(), self.caches, s0.nbytes, C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_step_multi failed (code {rc}): {lib.eec_decoder_step_last_error().decode(errors='replace')}")
+            tok.record_stream(stream)
+            if par is not None:
+                par.record_stream(stream)
+        self.s += 1
+        self.rows = R
+        for s in self.sessions:  # a session that joined a group is advanced only through it
+            s.s, s.rows = self.s, R
+        return out
+
+
 class full_conformer(_HipEncoderMixin, nn.Module):
     """AED model: HIP encoder + the attention decoder.  Inference (``_decoder_``, ``forward`` without autograd) runs the
     decoder on the hand-written path too (csrc/decoder.hip); with autograd the decoder is the reference's
@@ -959,6 +1012,16 @@ class full_conformer(_HipEncoderMixin, nn.Module):
         if nbytes == 0:
             return None
         return DecoderSession(self, ps, d_ff, V, enc2, int(max_steps), nbytes)
+
+    def decoder_session_group(self, encs: Sequence[Tensor], layer_ns: Sequence[int], max_steps: int) -> Optional["DecoderSessionGroup"]:
+        """Sessions for exits ``layer_ns`` of one utterance (``encs[i]``: that exit's encoder output), advanced together by
+        ``group.step``; None when a session is not available or there are more than 8 exits."""
+        if not 1 <= len(layer_ns) <= DecoderSessionGroup.MAX or len(encs) != len(layer_ns):
+            return None
+        sessions = [self.decoder_session(e, n, max_steps) for e, n in zip(encs, layer_ns)]
+        if any(s is None for s in sessions):
+            return None
+        return DecoderSessionGroup(sessions)
 
     def _decoder_(self, trg: Tensor, enc: Tensor, layer_n: int) -> Tensor:
         idx = (int(layer_n) if 1 <= int(layer_n) <= self._cfg.n_exits else self._cfg.n_exits) - 1

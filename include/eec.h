@@ -332,6 +332,13 @@ int eec_decoder_begin(const eec_decoder_params* p, int d_model, int n_heads, int
 int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* last_tokens,
                      const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax, float* out, void* cache,
                      size_t cache_bytes, void* stream);
+/* The same step for n <= 8 sessions at once -- the E exits of one utterance, which inference.py:44-51 decodes one after the other:
+ * every launch of the step covers all sessions (one more grid dimension), so E searches cost the launches of one.  ps / caches: HOST
+ * arrays of n pointers (sessions of one decoder geometry, each begun with eec_decoder_begin); last_tokens [n][R], parent [n][R] | NULL,
+ * out [n][R][V]; R, R_prev and s are common to the sessions (they advance in lockstep). */
+int eec_decoder_step_multi(int n, const eec_decoder_params* const* ps, int d_model, int n_heads, int d_ff, int vocab, int pad_idx,
+                           const int64_t* last_tokens, const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax,
+                           float* out, void* const* caches, size_t cache_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -682,6 +682,64 @@ def test_aed_beam_search_with_and_without_the_kv_cache():
     assert (torch.stack(sa).cpu().sort().values - torch.stack(sb).cpu().sort().values).abs().max().item() < 1e-3
 
 
+def test_aed_exits_in_lockstep_match_the_exit_by_exit_search():
+    """The exits of one utterance decoded together (eec_decoder_step_multi: every launch covers all sessions;
+    BeamInference.beam_search_exits / decode_all_exits) against the same searches run exit by exit: a group step returns
+    bit for bit what the sessions return one at a time, the searches return the same beams; the lockstep declines (None)
+    when EOS could finalise beams."""
+    import os
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import make_golden as G
+    from early_exit_transformer_amd.beam import BeamInference
+    z = np.load(os.path.join(GOLDEN, "aed_greedy.npz"))
+    kw = eval(str(z["kwargs"]))
+    fc = full_conformer(trg_pad_idx=126, enc_voc_size=256, max_len=2000, features_length=80, drop_prob=0.1, device="cuda",
+                        n_dec_layers=int(z["n_dec_layers"]), **kw).eval()
+    fc.load_state_dict(G.aed_state_dict(fc, int(z["seed"])), strict=True)
+    fc = fc.cuda()
+    E = kw["n_enc_exits"]
+    g = torch.Generator().manual_seed(5)
+    encs = [torch.randn(1, 45, kw["d_model"], generator=g).cuda() for _ in range(E)]
+    exits = list(range(1, E + 1))
+    # group step == single steps
+    group = fc.decoder_session_group(encs, exits, 6)
+    singles = [fc.decoder_session(encs[e], exits[e], 6) for e in range(E)]
+    assert group is not None
+    tok = torch.full((E, 1), 1, dtype=torch.long, device="cuda")
+    parent = None
+    for s in range(6):
+        got = group.step(tok, parent)
+        for e in range(E):
+            want = singles[e].step(tok[e], None if parent is None else parent[e])
+            assert torch.equal(got[e], want), (s, e)
+        R = 7 if s % 2 == 0 else 4
+        parent = torch.randint(0, tok.size(1), (E, R), generator=g).cuda()
+        tok = torch.randint(3, 256, (E, R), generator=g).cuda()
+    # searches
+    inf = BeamInference()
+    args = dict(vocab_size=256, max_length=11, SOS_token=1, EOS_token=2, PAD_token=126, beam_size=10, pen_alpha=0.6)
+    together = inf.beam_search_exits(fc, encs, exits, **args)
+    assert together is not None and len(together) == E
+    for e in range(E):
+        ta, sa, ba = inf.beam_search(fc, encs[e], exits[e], **args)
+        tb, sb, bb = together[e]
+        sa_, sb_ = torch.stack(sa).cpu(), torch.stack(sb).cpu()
+        assert (sa_.sort().values - sb_.sort().values).abs().max().item() < 1e-4
+        gaps = (sa_.sort().values[1:] - sa_.sort().values[:-1]).abs().min().item()
+        if gaps > 1e-3:
+            assert [t.tolist() for t in ta] == [t.tolist() for t in tb] and ba == bb, e
+    assert inf.beam_search_exits(fc, encs, exits, **dict(args, min_length=3)) is None  # EOS could finalise beams: exit by exit
+    # decode_all_exits takes the lockstep by itself and agrees with the exit-by-exit path
+    spec = torch.rand(80, 131, generator=g).cuda() * 3
+    vlen = torch.tensor(131)
+    kw2 = dict(vocab_size=256, SOS_token=1, EOS_token=2, PAD_token=126, pen_alpha=0.6, max_length=9)
+    a = inf.decode_all_exits(fc, spec, vlen, beam_size=5, **kw2)
+    b = inf.decode_all_exits(fc, spec, vlen, beam_size=5, kv_cache=False, **kw2)
+    assert len(a) == E and sum(x == y for x, y in zip(a, b)) >= E - 1  # a near-tie may flip one search
+
+
 def test_aed_beam_search_golden():
     """inference.py:18-62 (evaluate_batch_ae) end to end on the product: ONE HIP encoder run for all exits, the HIP
     decoder (eec_decoder_forward) per step, BeamInference.beam_search (beam 10) on the device.  Fixture: the reference's

@@ -44,8 +44,18 @@ with torch.no_grad():
             sess.step(last, par)
         d, dc = avg(lambda: sess.step(last, par), n=20)
         print(f"cached step at position {sess.s - 10}..{sess.s}: {d * 1e3:.3f} ms per step; CPU-side issue time {dc * 1e3:.3f} ms")
+    encs = [torch.randn(1, 256, 256, device="cuda") for _ in range(6)]
+    group = fc.decoder_session_group(encs, list(range(1, 7)), 2000)
+    last6, par6 = last.repeat(6, 1), par.repeat(6, 1)
+    group.step(last6[:, :1])
+    while group.s < 40:
+        group.step(last6, par6)
+    d, dc = avg(lambda: group.step(last6, par6), n=20)
+    print(f"cached step of 6 exits in lockstep at position {group.s - 10}..{group.s}: {d * 1e3:.3f} ms per step of all six; CPU-side issue time {dc * 1e3:.3f} ms")
     inf = BeamInference()
     kw = dict(vocab_size=256, SOS_token=1, EOS_token=2, PAD_token=126, pen_alpha=1.0, beam_size=10, max_length=85)
     for cached in (True, False):
         d, _ = avg(lambda: inf.beam_search(fc, enc, 1, kv_cache=cached, **kw), n=3)
         print(f"beam search, 85 steps, kv_cache={cached}: {d * 1e3:.1f} ms = {d / 85 * 1e3:.3f} ms per step")
+    d, _ = avg(lambda: inf.beam_search_exits(fc, encs, list(range(1, 7)), **kw), n=3)
+    print(f"beam search of 6 exits in lockstep, 85 steps: {d * 1e3:.1f} ms = {d / 85 * 1e3:.3f} ms per step of all six")
