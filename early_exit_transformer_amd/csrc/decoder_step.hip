@@ -187,7 +187,13 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(Group<SkinnyArgs> gr
     }
   }
 #pragma unroll
-  for (int r = 0; r < kRows; ++r) acc[r] = KL == 16 ? row16_sum(acc[r]) : wave64_sum(acc[r]);
+  for (int r = 0; r < kRows; ++r) {
+    if (KL == 64) acc[r] = wave64_sum(acc[r]);
+    else {
+      acc[r] = row16_sum(acc[r]);
+      if (KL == 32) acc[r] += __shfl_xor(acc[r], 16, 64);
+    }
+  }
   if (!writer) return;
   float v = 0.0f;
 #pragma unroll
@@ -201,14 +207,21 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(Group<SkinnyArgs> gr
 // the n sessions of a group share every shape (N, K, R): only pointers differ
 hipError_t skinny_linear(const Group<SkinnyArgs>& g, int n, hipStream_t st) {
   const SkinnyArgs& a = g.a[0];
-  const size_t lds = (size_t)(kRows + 2) * a.K * sizeof(float);
-  if (a.N < 1024) {  // a column per wave: N / 4 workgroups
-    if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<64>, (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(skinny_linear_kernel<64>, dim3((a.N + 3) / 4, n), dim3(256), lds, st, g);
-  } else {
-    if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<16>, (int)lds); e != hipSuccess) return e;
-    hipLaunchKernelGGL(skinny_linear_kernel<16>, dim3((a.N + 15) / 16, n), dim3(256), lds, st, g);
-  }
+  const size_t lds = (size_t)(a.ln_g ? kRows + 2 : a.R) * a.K * sizeof(float);
+  // k-lanes per column: 64 (a column per wave) spreads a narrow output over many workgroups; fewer, wider workgroups when
+  // the group of sessions would otherwise exceed about two per CU (one when the rows take more than 64 KB of LDS)
+  int kl = a.N >= 1024 ? 16 : 64;
+  const int limit = lds > 65536 ? 256 : 512;
+  while (kl > 16 && n * ((a.N + 256 / kl - 1) / (256 / kl)) > limit) kl >>= 1;
+#define EECS_SKINNY(KLv)                                                                                                  \
+  do {                                                                                                                    \
+    if (hipError_t e = eec::ensure_max_lds((const void*)skinny_linear_kernel<KLv>, (int)lds); e != hipSuccess) return e;  \
+    hipLaunchKernelGGL(skinny_linear_kernel<KLv>, dim3((a.N + 256 / KLv - 1) / (256 / KLv), n), dim3(256), lds, st, g);  \
+  } while (0)
+  if (kl == 64) EECS_SKINNY(64);
+  else if (kl == 32) EECS_SKINNY(32);
+  else EECS_SKINNY(16);
+#undef EECS_SKINNY
   return hipGetLastError();
 }
 

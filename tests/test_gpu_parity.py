@@ -685,7 +685,8 @@ def test_aed_beam_search_with_and_without_the_kv_cache():
 def test_aed_exits_in_lockstep_match_the_exit_by_exit_search():
     """The exits of one utterance decoded together (eec_decoder_step_multi: every launch covers all sessions;
     BeamInference.beam_search_exits / decode_all_exits) against the same searches run exit by exit: a group step returns
-    bit for bit what the sessions return one at a time, the searches return the same beams; the lockstep declines (None)
+    what the sessions return one at a time (to fp32 summation order: the tiling follows the group size), the searches return
+    the same beams; the lockstep declines (None)
     when EOS could finalise beams."""
     import os
     import sys
@@ -713,7 +714,7 @@ def test_aed_exits_in_lockstep_match_the_exit_by_exit_search():
         got = group.step(tok, parent)
         for e in range(E):
             want = singles[e].step(tok[e], None if parent is None else parent[e])
-            assert torch.equal(got[e], want), (s, e)
+            assert (got[e] - want).abs().max().item() < 2e-6 * max(10.0, want.abs().max().item()), (s, e)  # other tiling, fp32 order
         R = 7 if s % 2 == 0 else 4
         parent = torch.randint(0, tok.size(1), (E, R), generator=g).cuda()
         tok = torch.randint(3, 256, (E, R), generator=g).cuda()
