@@ -208,10 +208,11 @@ __global__ __launch_bounds__(256) void skinny_linear_kernel(Group<SkinnyArgs> gr
 hipError_t skinny_linear(const Group<SkinnyArgs>& g, int n, hipStream_t st) {
   const SkinnyArgs& a = g.a[0];
   const size_t lds = (size_t)(a.ln_g ? kRows + 2 : a.R) * a.K * sizeof(float);
-  // k-lanes per column: 64 (a column per wave) spreads a narrow output over many workgroups; fewer, wider workgroups when
-  // the group of sessions would otherwise exceed about two per CU (one when the rows take more than 64 KB of LDS)
+  // k-lanes per column: 64 (a column per wave) spreads a narrow output over many workgroups -- the per-workgroup chain of
+  // memory round trips is what a call costs (measured on the d_ff-long product of six sessions: 31 / 21 / 17 us at 96 / 192 /
+  // 384 workgroups) -- down to 16 when the group of sessions would exceed about two workgroups per CU
   int kl = a.N >= 1024 ? 16 : 64;
-  const int limit = lds > 65536 ? 256 : 512;
+  const int limit = 512;
   while (kl > 16 && n * ((a.N + 256 / kl - 1) / (256 / kl)) > limit) kl >>= 1;
 #define EECS_SKINNY(KLv)                                                                                                  \
   do {                                                                                                                    \
