@@ -537,16 +537,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     const int c = lane + 64 * i;
     gam[i] = c < D ? g[c] : 0.0f, dg[i] = 0.0f, db[i] = 0.0f;
   }
-  for (int row = r_begin + w; row < r_end; row += 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NE], dyv[NE], rv[NE], c1 = 0.0f, c2 = 0.0f;
+  // a wave walks its rows one after the other and every row ends in two wave reductions: the next row's operands are
+  // requested before the current row is reduced, or each row costs a full trip to memory
+  struct Row {
+    float x[NE], dy[NE], r[NE], mu, rs;
+  };
+  auto fetch = [&](int row, Row& o) __attribute__((always_inline)) {
+    o.mu = mean[row], o.rs = rstd[row];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int c = lane + 64 * i;
       const bool ok = c < D;
-      xh[i] = ok ? (x[(long)row * D + c] - mu) * rs : 0.0f;
-      dyv[i] = ok ? dy[(long)row * D + c] : 0.0f;
-      rv[i] = (ok && dres) ? dres[(long)row * D + c] : 0.0f;
+      o.x[i] = ok ? x[(long)row * D + c] : 0.0f;
+      o.dy[i] = ok ? dy[(long)row * D + c] : 0.0f;
+      o.r[i] = (ok && dres) ? dres[(long)row * D + c] : 0.0f;
+    }
+  };
+  Row cur{}, nxt{};
+  int row = r_begin + w;
+  if (row < r_end) fetch(row, cur);
+  for (; row < r_end; row += 4) {
+    if (row + 4 < r_end) fetch(row + 4, nxt);
+    const float mu = cur.mu, rs = cur.rs;
+    float xh[NE], dyv[NE], c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const bool ok = lane + 64 * i < D;
+      xh[i] = ok ? (cur.x[i] - mu) * rs : 0.0f;
+      dyv[i] = cur.dy[i];
       const float t = dyv[i] * gam[i];
       c1 += t, c2 += t * xh[i];
       dg[i] += dyv[i] * xh[i], db[i] += dyv[i];
@@ -555,11 +573,86 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int c = lane + 64 * i;
-      if (c < D) dx[(long)row * D + c] = rs * (dyv[i] * gam[i] - c1 - xh[i] * c2) + rv[i];
+      if (c < D) dx[(long)row * D + c] = rs * (dyv[i] * gam[i] - c1 - xh[i] * c2) + cur.r[i];
     }
+    cur = nxt;
   }
 #pragma unroll
   for (int i = 0; i < NE; ++i) red[w][0][lane + 64 * i] = dg[i], red[w][1][lane + 64 * i] = db[i];
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    part[((long)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+    part[((long)blockIdx.x * 2 + 1) * D + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+  }
+}
+// the same for D % 4 == 0 with 16-byte accesses: lane l owns columns 4 l + 256 i .. + 3
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_v4_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ part, int M, int D) {
+  __shared__ float red[4][2][256 * NV];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int rpb = (M + gridDim.x - 1) / gridDim.x, r_begin = blockIdx.x * rpb, r_end = min(M, r_begin + rpb);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gam[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = 4 * lane + 256 * i;
+    gam[i] = c < D ? *reinterpret_cast<const float4*>(g + c) : z4, dg[i] = z4, db[i] = z4;
+  }
+  struct Row {
+    float4 x[NV], dy[NV], r[NV];
+    float mu, rs;
+  };
+  auto fetch = [&](int row, Row& o) __attribute__((always_inline)) {
+    o.mu = mean[row], o.rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * lane + 256 * i;
+      const bool ok = c < D;
+      o.x[i] = ok ? *reinterpret_cast<const float4*>(x + (long)row * D + c) : z4;
+      o.dy[i] = ok ? *reinterpret_cast<const float4*>(dy + (long)row * D + c) : z4;
+      o.r[i] = (ok && dres) ? *reinterpret_cast<const float4*>(dres + (long)row * D + c) : z4;
+    }
+  };
+  Row cur{}, nxt{};
+  int row = r_begin + w;
+  if (row < r_end) fetch(row, cur);
+  for (; row < r_end; row += 4) {
+    if (row + 4 < r_end) fetch(row + 4, nxt);
+    const float mu = cur.mu, rs = cur.rs;
+    float4 xh[NV];
+    float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const bool ok = 4 * lane + 256 * i < D;
+      const float4 v = cur.x[i], d = cur.dy[i];
+      xh[i] = ok ? make_float4((v.x - mu) * rs, (v.y - mu) * rs, (v.z - mu) * rs, (v.w - mu) * rs) : z4;
+      const float tx = d.x * gam[i].x, ty = d.y * gam[i].y, tz = d.z * gam[i].z, tw = d.w * gam[i].w;
+      c1 += (tx + ty) + (tz + tw);
+      c2 += (tx * xh[i].x + ty * xh[i].y) + (tz * xh[i].z + tw * xh[i].w);
+      dg[i].x += d.x * xh[i].x, dg[i].y += d.y * xh[i].y, dg[i].z += d.z * xh[i].z, dg[i].w += d.w * xh[i].w;
+      db[i].x += d.x, db[i].y += d.y, db[i].z += d.z, db[i].w += d.w;
+    }
+    c1 = wave_sum(c1) / D, c2 = wave_sum(c2) / D;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = 4 * lane + 256 * i;
+      if (c < D) {
+        const float4 d = cur.dy[i];
+        float4 o;
+        o.x = rs * (d.x * gam[i].x - c1 - xh[i].x * c2) + cur.r[i].x, o.y = rs * (d.y * gam[i].y - c1 - xh[i].y * c2) + cur.r[i].y;
+        o.z = rs * (d.z * gam[i].z - c1 - xh[i].z * c2) + cur.r[i].z, o.w = rs * (d.w * gam[i].w - c1 - xh[i].w * c2) + cur.r[i].w;
+        *reinterpret_cast<float4*>(dx + (long)row * D + c) = o;
+      }
+    }
+    cur = nxt;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    *reinterpret_cast<float4*>(&red[w][0][4 * lane + 256 * i]) = dg[i];
+    *reinterpret_cast<float4*>(&red[w][1][4 * lane + 256 * i]) = db[i];
+  }
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     part[((long)blockIdx.x * 2 + 0) * D + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
@@ -570,6 +663,12 @@ hipError_t launch_ln_bwd(const float* dy, const float* x, const float* g, const 
                          float* dx, float* part, int M, int D, hipStream_t st) {
   if (D > 64 * kLnMax) return hipErrorInvalidValue;
   const dim3 grid(ln_bwd_blocks(M));
+  if (D % 4 == 0) {
+    if (D <= 256) hipLaunchKernelGGL(ln_bwd_v4_kernel<1>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+    else if (D <= 512) hipLaunchKernelGGL(ln_bwd_v4_kernel<2>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+    else hipLaunchKernelGGL(ln_bwd_v4_kernel<4>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
+    return hipGetLastError();
+  }
   if (D <= 256) hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
   else if (D <= 512) hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
   else hipLaunchKernelGGL(ln_bwd_kernel<16>, grid, dim3(256), 0, st, dy, x, g, mean, rstd, dres, dx, part, M, D);
