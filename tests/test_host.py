@@ -265,9 +265,74 @@ class _ToyDecoderModel:
         self.emb = torch.randn(V, 16, generator=g)
         self.out = torch.randn(16, V, generator=g) * 2
 
-    def _decoder_(self, trg, enc, layer_n):
-        h = torch.cumsum(self.emb[trg] * torch.linspace(1.0, 2.0, trg.size(1)).view(1, -1, 1), dim=1) + enc.mean(dim=1, keepdim=True)[..., :16]
+    def _head(self, h, layer_n):
         return torch.log_softmax(torch.tanh(h) @ self.out * (1.0 + 0.1 * layer_n), dim=-1)
+
+    def _decoder_(self, trg, enc, layer_n):
+        w = 1.0 + 0.07 * torch.arange(trg.size(1), dtype=torch.float32)
+        h = torch.cumsum(self.emb[trg] * w.view(1, -1, 1), dim=1) + enc.mean(dim=1, keepdim=True)[..., :16]
+        return self._head(h, layer_n)
+
+
+class _ToySession:
+    """The toy model decoded step-wise, with the interface of model.DecoderSession: the running prefix state of every beam
+    follows the ``parent`` rows, as the key / value cache's ancestry does."""
+
+    max_beams = 16
+
+    def __init__(self, model, enc, layer_n):
+        self.m, self.n, self.base, self.state, self.s = model, layer_n, enc.mean(dim=1)[..., :16], None, 0
+
+    def step(self, last_tokens, parent=None):
+        prev = torch.zeros(1, 16) if self.state is None else self.state
+        if self.s > 0:
+            prev = prev[parent if parent is not None else torch.arange(last_tokens.numel())]
+        self.state = prev + self.m.emb[last_tokens] * (1.0 + 0.07 * self.s)
+        self.s += 1
+        return self.m._head(self.state + self.base, self.n)
+
+
+class _ToySessionModel(_ToyDecoderModel):
+    def decoder_session(self, enc, layer_n, max_steps):
+        return _ToySession(self, enc, layer_n)
+
+    def decoder_session_group(self, encs, layer_ns, max_steps):
+        sessions = [_ToySession(self, e, n) for e, n in zip(encs, layer_ns)]
+
+        class Group:
+            max_beams = 16
+
+            def step(self, last_tokens, parent=None):
+                return torch.stack([s.step(last_tokens[i], None if parent is None else parent[i]) for i, s in enumerate(sessions)])
+        return Group()
+
+
+@pytest.mark.parametrize("min_length,max_length,beam", [(300, 12, 5), (2, 12, 5), (0, 9, 3)])
+def test_beam_search_over_decoder_sessions_equals_the_whole_prefix_search(min_length, max_length, beam):
+    """The step-wise bookkeeping of BeamInference (``parent`` rows handed to a decoder session, also after EOS has removed
+    beams; the exits of an utterance in lockstep) on a toy session model against the whole-prefix search of the same model,
+    which the next test pins to the reference's algorithm."""
+    from early_exit_transformer_amd.beam import BeamInference
+    V, eos = 11, 2
+    model = _ToySessionModel(V)
+    g = torch.Generator().manual_seed(3)
+    encs = [torch.randn(1, 7, 16, generator=g) for _ in range(3)]
+    inf = BeamInference()
+    kw = dict(vocab_size=V, max_length=max_length, min_length=min_length, SOS_token=1, EOS_token=eos, PAD_token=0, beam_size=beam, pen_alpha=1.0)
+    per_exit = []
+    for n, enc in enumerate(encs, start=1):
+        ta, sa, ba = inf.beam_search(model, enc, n, **kw)
+        tb, sb, bb = inf.beam_search(model, enc, n, kv_cache=False, **kw)
+        assert ba == bb and [t.tolist() for t in ta] == [t.tolist() for t in tb]
+        assert torch.allclose(torch.stack(sa), torch.stack(sb), atol=1e-5)
+        per_exit.append((ta, sa, ba))
+    together = inf.beam_search_exits(model, encs, [1, 2, 3], **kw)
+    if max_length - 1 > min_length:
+        assert together is None  # EOS can finalise beams: the exits' beam counts may diverge, no lockstep
+    else:
+        for (ta, sa, ba), (tb, sb, bb) in zip(per_exit, together):
+            assert ba == bb and [t.tolist() for t in ta] == [t.tolist() for t in tb]
+            assert torch.allclose(torch.stack(sa), torch.stack(list(sb)), atol=1e-5)
 
 
 @pytest.mark.parametrize("min_length,max_length,beam", [(300, 12, 5), (2, 12, 5), (0, 9, 3), (4, 6, 4)])
