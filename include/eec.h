@@ -286,7 +286,8 @@ int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, 
  * cross-attention over enc [Bm][Tq][D], ReLU feed-forward) and the shared final LayerNorm.  fp32 parameters are read in
  * place (state_dict tensors); arithmetic as the training GEMM (passes 3: bf16 hi/lo split, ~1e-5 of fp32).  trg: int64
  * [Bm][S]; positions equal to pad_idx are masked as keys.  The caller's beam search (util/beam_infer.py:198-307) stays
- * above this call: one call per decoding step, as the reference (no KV cache).  enc_shared != 0: every one of the Bm rows attends
+ * above this call: one call per decoding step on the whole prefix, as the reference (the step-wise form with a key / value
+ * cache is eec_decoder_begin / eec_decoder_step below).  enc_shared != 0: every one of the Bm rows attends
  * to the SAME memory enc [1][Tq][D] (beam search expands one utterance over its beams): its keys / values are projected once. */
 typedef struct eec_decoder_layer_params {
   const float *sa_in_w, *sa_in_b;   /* self_attn.in_proj_{weight,bias}      [3D,D],[3D] */
