@@ -295,6 +295,14 @@ int eec_encoder_lengths(const int64_t* lengths, int B, int Tq, int32_t* enc_len,
   return 0;
 }
 
+int eec_upload_i64_max(void) { return kUploadMax; }
+
+int eec_upload_i64(const int64_t* host, int n, int64_t* dev, void* stream) {
+  if (!host || !dev || n <= 0 || n > kUploadMax) return fail(EEC_ERR_BAD_ARG, "eec_upload_i64: 1 .. 480 values");
+  EEC_HIP(launch_upload_i64((const long long*)host, n, (long long*)dev, (hipStream_t)stream));
+  return 0;
+}
+
 int eec_encoder_create(const eec_config* cfg, eec_encoder** out) {
   if (!cfg || !out) return fail(EEC_ERR_BAD_ARG, "null argument");
   if (int rc = check_cfg(*cfg)) return rc;

@@ -7,6 +7,8 @@ namespace eec {
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, DEVICE): the attribute is per device, so a
 // process-wide flag would leave the > 64 KiB launches of a second device failing.  Thread-safe.
 hipError_t ensure_max_lds(const void* kernel, int bytes);
+constexpr int kUploadMax = 480;  // int64 values that fit a kernel's argument block
+hipError_t launch_upload_i64(const long long* host, int n, long long* dev, hipStream_t st);
 
 struct FfnArgs {
   float* x;  // [M][D] fp32, updated in place

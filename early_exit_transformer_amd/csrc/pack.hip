@@ -156,6 +156,24 @@ hipError_t launch_enc_lengths(const long long* lengths, int B, int Tq, int* enc_
   return hipGetLastError();
 }
 
+// Small host arrays (the collate's `lengths`, train.py:34) reach the device inside a kernel's ARGUMENT block: no DMA and no
+// cross-queue dependency on the stream (a host-to-device copy in front of the forward leaves a ~35 us hole behind it).
+struct UploadArgs {
+  long long v[kUploadMax];
+};
+__global__ void upload_i64_kernel(UploadArgs a, int n, long long* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a.v[i];
+}
+hipError_t launch_upload_i64(const long long* host, int n, long long* dev, hipStream_t st) {
+  if (n < 0 || n > kUploadMax) return hipErrorInvalidValue;
+  UploadArgs a;
+  for (int i = 0; i < n; ++i) a.v[i] = host[i];
+  for (int i = n; i < kUploadMax; ++i) a.v[i] = 0;
+  hipLaunchKernelGGL(upload_i64_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a, n, dev);
+  return hipGetLastError();
+}
+
 __global__ void fill_int_kernel(int* dst, int n, int v) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = v;

@@ -59,6 +59,24 @@ def _layer_params(ptr, prefix: str, n_groups: int, n_layers: int):
     return layers
 
 
+def _to_device(t: Tensor, dev: torch.device, dtype: torch.dtype = torch.int64) -> Tensor:
+    """``t.to(dev, dtype).contiguous()``; a small CPU int64 tensor (the collate's ``lengths`` are CPU tensors in the
+    reference, train.py:34,54) travels in a kernel's argument block instead (eec_upload_i64): a host-to-device copy in front
+    of the forward drains the host's launch queue and leaves a hole on the stream once per step."""
+    if t.is_cuda or dev.type != "cuda" or dtype != torch.int64 or t.numel() == 0:
+        return t.to(device=dev, dtype=dtype).contiguous()
+    lib = capi.load()
+    if t.numel() > lib.eec_upload_i64_max():
+        return t.to(device=dev, dtype=dtype).contiguous()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev.index is None else dev
+    host = t.to(torch.int64).contiguous()
+    out = torch.empty(host.shape, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        capi.check(lib.eec_upload_i64(host.data_ptr(), host.numel(), out.data_ptr(),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "eec_upload_i64")
+    return out
+
+
 class _HipEncoderMixin:
     """Owns the libeec encoder handle, the packed-weight cache and the workspace."""
 
@@ -199,7 +217,7 @@ class _HipEncoderMixin:
             if Tq <= 0:
                 raise ValueError("T too short for two k=3 s=2 convolutions")
             src = src.contiguous().float()
-            len_dev = lengths.to(device=dev, dtype=torch.int64).contiguous()
+            len_dev = _to_device(lengths, dev)
             E, D, V = self._cfg.n_exits, self._cfg.d_model, self._cfg.vocab
             if n_groups is not None:
                 if stop_after >= 0:
@@ -272,7 +290,7 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         mine = ("conv_subsample.", "conformer.", self._head_attr + ".")
         named = [(n, p) for n, p in self.named_parameters() if n.startswith(mine)]
         names = tuple(n for n, _ in named)
-        len_dev = lengths.to(device=src.device, dtype=torch.int64).contiguous()
+        len_dev = _to_device(lengths, src.device)
         return _EncoderTrainFn.apply(self, src.contiguous().float(), len_dev, names, want_taps, *[p for _, p in named])
 
     def _forward_heads_trainable(self, src: Tensor, lengths: Tensor) -> Tensor:
@@ -389,7 +407,7 @@ class Splitformer(Early_conformer):
             lib = capi.load()
             B, Tq, D = x.shape
             E, V = self._cfg.n_exits, self._cfg.vocab
-            mel_len = lengths.to(device=dev, dtype=torch.int64)
+            mel_len = _to_device(lengths, dev)
             base = torch.clamp(mel_len / 4, max=Tq).to(torch.int32)
             out = torch.empty((E, B, Tq, V), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -481,7 +499,7 @@ class Early_zipformer(_HipEncoderMixin, nn.Module):
             enc = torch.empty((B, T1, D), dtype=torch.float32, device=dev)
             capi.check(lib.eec_encoder_stem1_forward(self._enc, src.data_ptr(), B, T, enc.data_ptr(), C.c_void_p(stream)),
                        "eec_encoder_stem1_forward")
-            mel_len = lengths.to(device=dev, dtype=torch.int64)
+            mel_len = _to_device(lengths, dev)
             base = torch.clamp(mel_len / 2, max=T1).to(torch.int32)
             self._group(self._enc, 0, enc, base)
             self._group(self._enc, 1, enc, base)
@@ -562,8 +580,8 @@ def _ctc_prepare(enc_out: Tensor, targets: Tensor, target_len: Tensor):
         raise RuntimeError("exit_ctc_losses runs on a HIP device only")
     enc_out = enc_out.contiguous().float()
     dev = enc_out.device
-    tg = targets.to(device=dev, dtype=torch.int64).contiguous()
-    tl = target_len.to(device=dev, dtype=torch.int64).contiguous()
+    tg = _to_device(targets, dev)
+    tl = _to_device(target_len, dev)
     return enc_out, tg, tl
 
 

@@ -120,6 +120,12 @@ int eec_out_frames(int T);
  * keys t >= enc_len[b] are masked in every attention of the stack (torchaudio _lengths_to_padding_mask).  The forward
  * entry points compute it internally; this entry exposes the integers (tests compare them bit for bit). */
 int eec_encoder_lengths(const int64_t* lengths, int B, int Tq, int32_t* enc_len, void* stream);
+/* A small HOST int64 array (the `lengths` the reference's collate hands to forward() as a CPU tensor, train.py:34,54) -> device
+ * memory through a kernel's argument block: stream-ordered like a copy, but no DMA and no cross-queue dependency in front of the
+ * forward.  n <= eec_upload_i64_max() (480); the host array is read before the call returns. */
+int eec_upload_i64_max(void);
+int eec_upload_i64(const int64_t* host, int n, int64_t* dev, void* stream);
+
 
 /* Replaces Early_conformer.__init__ (early_exit.py:567-615) for the encoder stack. */
 int eec_encoder_create(const eec_config* cfg, eec_encoder** out);
