@@ -11,6 +11,9 @@
 //   skinny_linear (LN1 -> in_proj)  step_attn<self>  skinny_linear (out_proj, += x)
 //   skinny_linear (LN2 -> q)        step_attn<cross> skinny_linear (out_proj, += x)
 //   skinny_linear (LN3 -> linear1 -> ReLU)           skinny_linear (linear2, += x)
+// A step is bound by that launch count (a dependent launch costs 4 - 6 us here), not by its work, so every kernel takes a
+// GROUP of up to 8 sessions -- the exits of one utterance, whose searches are independent -- as one more grid dimension
+// (eec_decoder_step_multi): E searches for the launches of one.
 #include <algorithm>
 #include <string>
 
