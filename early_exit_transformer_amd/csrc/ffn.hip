@@ -323,7 +323,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
       sink_front = t;
     }
 #endif
+    TL_STAMP();  // front: weight requests issued
     dw_front<D, FNP>(smem, a.dw, M, row0);
+    TL_STAMP();  // front: depthwise planes written
     RowV<G::kQ> xr[RPW];  // residual rows: requested now, consumed after the pointwise-2 GEMM
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -333,11 +335,14 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     }
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();  // conv planes complete; the staged GLU rows / taps are dead
+    TL_STAMP();  // front: barrier
     f32x16 accp[MT][NW];
     pw2_gemm<D, FNP>(accp, smem, a.pw2, rp);
+    TL_STAMP();  // front: pointwise-2 done
     start_streams(wptrs(0));
     acc_swapped_to_etile<MT, NW>(lds_e, G::kELd, accp, 32 * NW * w);
     __syncthreads();  // tile complete; every wave is done reading the conv planes
+    TL_STAMP();  // front: exchange tile complete
     chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
   } else {
     const WPtrs W0 = wptrs(0);
