@@ -18,7 +18,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 from torch import Tensor
 
-from .model import ctc_beam_decode, greedy_ctc
+from .model import beam_select, ctc_beam_decode, greedy_ctc
 
 
 class GreedyCTCDecoder(torch.nn.Module):
@@ -83,6 +83,14 @@ class BeamInference:
         scores = torch.zeros(1, dtype=torch.float32, device=dev)
         final_tokens: List[Tensor] = []
         final_scores: List[Tensor] = []
+        if kv_cache and return_best_beam and encoder_output.is_cuda and encoder_output.size(0) == 1:
+            # no beam can finish inside max_length (the reference's defaults): the lockstep search with one member, whose
+            # per-step bookkeeping is one launch
+            one = self.beam_search_exits(model, [encoder_output], [layer_n], vocab_size=V, max_length=max_length, min_length=min_length,
+                                         SOS_token=sos, EOS_token=eos, PAD_token=self._arg(PAD_token, "trg_pad_idx"), beam_size=beam,
+                                         pen_alpha=alpha)
+            if one is not None:
+                return one[0]
         session = None
         if kv_cache and max_length >= 1 and hasattr(model, "decoder_session") and encoder_output.size(0) == 1:
             session = model.decoder_session(encoder_output, layer_n, max_length)
@@ -165,15 +173,25 @@ class BeamInference:
         if group is None or beam > group.max_beams:
             return None
         n, dev = len(layer_ns), encoder_outputs[0].device
-        tokens = torch.full((n, 1, 1), sos, dtype=torch.long, device=dev)  # [exits, live beams, s]
         scores = torch.zeros((n, 1), dtype=torch.float32, device=dev)
         parent: Optional[Tensor] = None
-        for i in range(max_length):
-            logp = group.step(tokens[:, :, -1], parent) / sequence_length_penalty(i + 1, alpha)
-            scores, idx = torch.topk((scores.unsqueeze(2) + logp).reshape(n, -1), beam, dim=1)
-            parent = torch.div(idx, V, rounding_mode="floor")
-            tok_idx = torch.remainder(idx, V)
-            tokens = torch.cat([torch.gather(tokens, 1, parent.unsqueeze(2).expand(-1, -1, tokens.size(2))), tok_idx.unsqueeze(2)], dim=2)
+        if dev.type == "cuda":  # top-k, parent / token split and the token gather of a step in one launch (eec_beam_select)
+            rows = max(beam, 1)
+            bufs = [torch.zeros((n, rows, max_length + 1), dtype=torch.long, device=dev) for _ in range(2)]
+            bufs[0][:, 0, 0] = sos
+            last = bufs[0][:, :1, 0].contiguous()
+            for i in range(max_length):
+                logp = group.step(last, parent)
+                scores, parent, last = beam_select(logp, scores, sequence_length_penalty(i + 1, alpha), beam, bufs[i & 1], bufs[(i + 1) & 1], i + 1)
+            tokens = bufs[max_length & 1][:, :beam]
+        else:
+            tokens = torch.full((n, 1, 1), sos, dtype=torch.long, device=dev)  # [exits, live beams, s]
+            for i in range(max_length):
+                logp = group.step(tokens[:, :, -1], parent) / sequence_length_penalty(i + 1, alpha)
+                scores, idx = torch.topk((scores.unsqueeze(2) + logp).reshape(n, -1), beam, dim=1)
+                parent = torch.div(idx, V, rounding_mode="floor")
+                tok_idx = torch.remainder(idx, V)
+                tokens = torch.cat([torch.gather(tokens, 1, parent.unsqueeze(2).expand(-1, -1, tokens.size(2))), tok_idx.unsqueeze(2)], dim=2)
         best = scores.argmax(dim=1).tolist()
         tokens_h = tokens.cpu()
         return [(list(tokens[e]), list(scores[e]), tokens_h[e, best[e]].tolist()) for e in range(n)]

@@ -88,7 +88,7 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
            "eec_train_forward", "eec_train_backward", "eec_train_gemm",
            "eec_decoder_last_error", "eec_decoder_workspace_bytes", "eec_decoder_forward",
-           "eec_decoder_step_last_error", "eec_decoder_step_max_beams", "eec_decoder_cache_bytes", "eec_decoder_begin", "eec_decoder_step", "eec_decoder_step_multi", "eec_upload_i64_max", "eec_upload_i64"]
+           "eec_decoder_step_last_error", "eec_decoder_step_max_beams", "eec_decoder_cache_bytes", "eec_decoder_begin", "eec_decoder_step", "eec_decoder_step_multi", "eec_upload_i64_max", "eec_upload_i64", "eec_beam_select"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
 _lib: Optional[C.CDLL] = None
@@ -173,6 +173,8 @@ def load() -> C.CDLL:
     lib.eec_decoder_step_multi.argtypes = [C.c_int, C.POINTER(C.POINTER(EecDecoderParams)), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                            C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p]
+    lib.eec_beam_select.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
     lib.eec_upload_i64.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.eec_encoder_set_profiling.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.eec_encoder_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]

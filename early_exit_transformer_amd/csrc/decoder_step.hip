@@ -378,6 +378,61 @@ hipError_t step_attn(const Group<StepAttnArgs>& g, int n, int R, int H, hipStrea
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The beam search's bookkeeping of one step (util/beam_infer.py:241-262) for every session of a group in one launch:
+//   cand = scores[r] + logp[r][v] / penalty over all (r, v);  the K best, best first (ties: the lower flat index);
+//   parent = index / V, token = index % V;  tokens_new[b] = tokens_old[parent[b]][0 .. len) + token[b].
+// One workgroup per session; the R * V candidates sit in LDS and are searched K times.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ logp, const float* __restrict__ scores_in, float penalty, int R,
+                                                          int V, int K, float* __restrict__ scores_out, long long* __restrict__ parent,
+                                                          long long* __restrict__ tok, const long long* __restrict__ tokens_old,
+                                                          long long* __restrict__ tokens_new, int len, int ld, int rows_ld) {
+  extern __shared__ float cand[];  // [R * V]
+  __shared__ float wv[4];
+  __shared__ int wi[4];
+  __shared__ int chosen[kRows];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = R * V;
+  const float* lp = logp + (long)e * n;
+  for (int i = tid; i < n; i += 256) cand[i] = scores_in[e * R + i / V] + lp[i] / penalty;
+  __syncthreads();
+  for (int b = 0; b < K; ++b) {
+    float best = -INFINITY;
+    int at = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float v = cand[i];
+      if (v > best) best = v, at = i;  // ascending i: the first of equal values stays
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = __shfl_xor(best, m, 64);
+      const int oi = __shfl_xor(at, m, 64);
+      if (ov > best || (ov == best && oi < at)) best = ov, at = oi;
+    }
+    if (lane == 0) wv[w] = best, wi[w] = at;
+    __syncthreads();
+    if (tid == 0) {
+      float bv = wv[0];
+      int bi = wi[0];
+      for (int k = 1; k < 4; ++k)
+        if (wv[k] > bv || (wv[k] == bv && wi[k] < bi)) bv = wv[k], bi = wi[k];
+      if (bi < 0 || bi >= n) bi = 0;  // nothing comparable (all NaN / -inf): stay in bounds
+      chosen[b] = bi;
+      scores_out[e * K + b] = bv;
+      parent[e * K + b] = bi / V;
+      tok[e * K + b] = bi % V;
+      cand[bi] = -INFINITY;
+    }
+    __syncthreads();
+  }
+  const long long* told = tokens_old + (long)e * rows_ld * ld;
+  long long* tnew = tokens_new + (long)e * rows_ld * ld;
+  for (int i = tid; i < K * (len + 1); i += 256) {
+    const int b = i / (len + 1), j = i - b * (len + 1);
+    tnew[(long)b * ld + j] = j < len ? told[(long)(chosen[b] / V) * ld + j] : (long long)(chosen[b] % V);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 thread_local std::string g_serr;
 int sfail(int code, const std::string& msg) {
   g_serr = msg;
@@ -544,6 +599,21 @@ int eec_decoder_step_multi(int n, const eec_decoder_params* const* ps, int d_mod
   } else {
     SRUN(linear([&](int i) { return SkinnyArgs{c[i].x, D, ps[i]->norm_w, ps[i]->norm_b, ps[i]->head_w, ps[i]->head_b, out + i * out_stride, vocab}; }, vocab, D, 0, 0));
   }
+  return 0;
+}
+
+int eec_beam_select(int n, int R, int V, int K, const float* logp, const float* scores_in, float penalty, float* scores_out, int64_t* parent,
+                    int64_t* tok, const int64_t* tokens_old, int64_t* tokens_new, int len, int ld, int rows_ld, void* stream) {
+  if (!logp || !scores_in || !scores_out || !parent || !tok || !tokens_old || !tokens_new) return sfail(EEC_ERR_BAD_ARG, "null argument");
+  if (n <= 0 || R <= 0 || R > kRows || V <= 0 || K <= 0 || K > kRows || K > (long)R * V || rows_ld < std::max(R, K) || len < 0 || ld < len + 1 ||
+      !(penalty > 0.0f))
+    return sfail(EEC_ERR_BAD_ARG, "eec_beam_select: 1 .. 16 beams in and out, token rows of at least len + 1");
+  const size_t lds = (size_t)R * V * sizeof(float);
+  if (lds > 150000) return sfail(EEC_ERR_UNSUPPORTED, "eec_beam_select: R * V candidates must fit the LDS");
+  SRUN(eec::ensure_max_lds((const void*)beam_select_kernel, (int)lds));
+  hipLaunchKernelGGL(beam_select_kernel, dim3(n), dim3(256), lds, (hipStream_t)stream, logp, scores_in, penalty, R, V, K, scores_out,
+                     (long long*)parent, (long long*)tok, (const long long*)tokens_old, (long long*)tokens_new, len, ld, rows_ld);
+  SRUN(hipGetLastError());
   return 0;
 }
 

@@ -797,6 +797,28 @@ class _EncoderTrainFn(torch.autograd.Function):
         return (None, None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])
 
 
+def beam_select(logp: Tensor, scores: Tensor, penalty: float, k: int, tokens_old: Tensor, tokens_new: Tensor, length: int):
+    """One step of beam-search bookkeeping for n searches in lockstep, in one launch (eec_beam_select): the ``k`` best of
+    ``scores[i, r] + logp[i, r, v] / penalty`` per search i, best first -> ``(scores [n, k], parent [n, k], token [n, k])``,
+    and ``tokens_new[i, b, :length + 1] = cat(tokens_old[i, parent[i, b], :length], token[i, b])``.  What
+    util/beam_infer.py:241-262 does with topk / index / cat, for every exit of an utterance at once."""
+    n, R, V = logp.shape
+    dev = logp.device
+    if tokens_old.shape != tokens_new.shape or tokens_old.dim() != 3 or tokens_old.size(0) != n:
+        raise ValueError("token buffers: two [n, rows, steps] int64 tensors")
+    out_s = torch.empty((n, k), dtype=torch.float32, device=dev)
+    parent = torch.empty((n, k), dtype=torch.int64, device=dev)
+    tok = torch.empty((n, k), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        lib = capi.load()
+        rc = lib.eec_beam_select(n, R, V, int(k), logp.contiguous().data_ptr(), scores.contiguous().data_ptr(), float(penalty), out_s.data_ptr(),
+                                 parent.data_ptr(), tok.data_ptr(), tokens_old.data_ptr(), tokens_new.data_ptr(), int(length),
+                                 tokens_old.size(2), tokens_old.size(1), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"eec_beam_select failed (code {rc}): {lib.eec_decoder_step_last_error().decode(errors='replace')}")
+    return out_s, parent, tok
+
+
 class DecoderSession:
     """One utterance's step-wise AED decoding state (include/eec.h, eec_decoder_begin / eec_decoder_step): ``step(tokens,
     parent)`` returns the log-probs of the NEXT token for every live beam, [R, V] -- what

@@ -346,6 +346,12 @@ int eec_decoder_step(const eec_decoder_params* p, int d_model, int n_heads, int 
 int eec_decoder_step_multi(int n, const eec_decoder_params* const* ps, int d_model, int n_heads, int d_ff, int vocab, int pad_idx,
                            const int64_t* last_tokens, const int64_t* parent, int R, int R_prev, int s, int Tq, int S_max, int log_softmax,
                            float* out, void* const* caches, size_t cache_bytes, void* stream);
+/* The bookkeeping of one beam-search step (util/beam_infer.py:241-262) for n searches in lockstep, one launch: over the R live beams'
+ * V next-token log-probs, cand = scores_in[r] + logp[r][v] / penalty; the K best, best first (ties: the lower r * V + v) ->
+ * scores_out [n][K], parent [n][K] (= index / V), tok [n][K] (= index % V); tokens_new[i][b][0 .. len] = tokens_old[i][parent][0 .. len)
+ * followed by tok.  Token buffers: [n][rows_ld][ld] int64, len tokens per beam so far.  R, K <= 16. */
+int eec_beam_select(int n, int R, int V, int K, const float* logp, const float* scores_in, float penalty, float* scores_out, int64_t* parent,
+                    int64_t* tok, const int64_t* tokens_old, int64_t* tokens_new, int len, int ld, int rows_ld, void* stream);
 
 #ifdef __cplusplus
 }

@@ -682,6 +682,40 @@ def test_aed_beam_search_with_and_without_the_kv_cache():
     assert (torch.stack(sa).cpu().sort().values - torch.stack(sb).cpu().sort().values).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("n,R,V,K,length", [(6, 10, 256, 10, 7), (1, 1, 256, 10, 1), (3, 16, 40, 16, 30), (2, 5, 11, 3, 4)])
+def test_beam_select_matches_the_torch_bookkeeping(n, R, V, K, length):
+    """eec_beam_select (top-k of score + log-prob / penalty over all beams and tokens, parent / token split, token gather:
+    util/beam_infer.py:241-262 for n searches at once) against the same step written with torch.topk / gather / cat;
+    ties go to the lower flat index and the output is ordered best first."""
+    from early_exit_transformer_amd.model import beam_select
+    g = torch.Generator().manual_seed(n * 1000 + R * V + K)
+    logp = torch.log_softmax(torch.randn(n, R, V, generator=g) * 3, dim=-1).cuda()
+    scores = (torch.randn(n, R, generator=g) * 2).cuda()
+    steps = length + 3
+    old = torch.randint(0, V, (n, max(R, K), steps), generator=g).cuda()
+    new = torch.full_like(old, -1)
+    penalty = 1.37
+    got_s, got_p, got_t = beam_select(logp, scores, penalty, K, old, new, length)
+    cand = (scores.unsqueeze(2) + logp / penalty).reshape(n, -1)
+    want_s, idx = torch.topk(cand, K, dim=1)
+    assert (got_s - want_s).abs().max().item() < 1e-5
+    assert bool((got_s[:, :-1] >= got_s[:, 1:]).all())
+    flat = got_p * V + got_t
+    assert bool(((got_p >= 0) & (got_p < R) & (got_t >= 0) & (got_t < V)).all())
+    assert all(len(set(row.tolist())) == K for row in flat.cpu())  # K distinct candidates
+    assert (cand.gather(1, flat) - got_s).abs().max().item() < 1e-5  # the reported scores are the chosen candidates' scores
+    want_tokens = torch.cat([torch.gather(old[:, :, :length], 1, got_p.unsqueeze(2).expand(-1, -1, length)), got_t.unsqueeze(2)], dim=2)
+    assert torch.equal(new[:, :K, :length + 1], want_tokens)
+    assert bool((new[:, :K, length + 1:] == -1).all())
+    # exact ties: every beam offers the same log-probs and the same score -> the lowest flat indices, in order
+    logp2 = logp[:, :1].expand(-1, R, -1).contiguous()
+    s2 = torch.zeros(n, R, device="cuda")
+    _, p2, t2 = beam_select(logp2, s2, 1.0, min(K, R), old, new, length)
+    top_tok = logp2[:, 0].argmax(dim=1)
+    assert torch.equal(t2, top_tok.unsqueeze(1).expand(-1, min(K, R)))
+    assert torch.equal(p2, torch.arange(min(K, R), device="cuda").unsqueeze(0).expand(n, -1))
+
+
 def test_aed_exits_in_lockstep_match_the_exit_by_exit_search():
     """The exits of one utterance decoded together (eec_decoder_step_multi: every launch covers all sessions;
     BeamInference.beam_search_exits / decode_all_exits) against the same searches run exit by exit: a group step returns
