@@ -716,6 +716,24 @@ def test_beam_select_matches_the_torch_bookkeeping(n, R, V, K, length):
     assert torch.equal(p2, torch.arange(min(K, R), device="cuda").unsqueeze(0).expand(n, -1))
 
 
+def test_small_host_tensors_reach_the_device_through_kernel_arguments():
+    """model._to_device: up to 480 int64 values of a CPU tensor travel in a kernel's argument block (eec_upload_i64), larger
+    or non-int64 tensors take the ordinary copy; values, shapes and dtypes are those of ``tensor.to(device)`` either way."""
+    from early_exit_transformer_amd.model import _to_device
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(0)
+    for shape in ((1,), (64,), (480,), (481,), (6, 80), (0,), (3, 5, 7)):
+        for dtype in (torch.int64, torch.int32):
+            t = torch.randint(-2**31, 2**31 - 1, shape, generator=g, dtype=torch.int64).to(dtype)
+            got = _to_device(t, dev)
+            assert got.device == dev and got.dtype == torch.int64 and got.shape == t.shape
+            assert torch.equal(got.cpu(), t.to(torch.int64))
+    big = torch.tensor([2**62 + 12345, -2**62 - 6789, 0])
+    assert torch.equal(_to_device(big, dev).cpu(), big)
+    on_dev = torch.arange(10, device=dev)
+    assert _to_device(on_dev, dev).data_ptr() == on_dev.data_ptr()
+
+
 def test_aed_exits_in_lockstep_match_the_exit_by_exit_search():
     """The exits of one utterance decoded together (eec_decoder_step_multi: every launch covers all sessions;
     BeamInference.beam_search_exits / decode_all_exits) against the same searches run exit by exit: a group step returns
