@@ -92,6 +92,43 @@ def launch_ranks(n, argv):
     return rc
 
 
+class RecordGuard:
+    """Exactly ONE record per run, whatever happens in the last (training-step) section: the main thread emits it when the
+    section is done; a rank that fails inside a step, or whose section does not finish in time (a hung collective), emits the
+    record as far as it got -- rank 0 only -- and ends the process with a NON-ZERO status without entering another collective
+    (its peers may be stuck in one; the launcher terminates them when it sees the status).  No re-exec, no retry in a
+    GPU-initialised process."""
+
+    def __init__(self, rank, line):
+        self.rank, self.line = rank, line
+        self._lock, self._emitted, self._done = threading.Lock(), False, threading.Event()
+
+    def emit(self, train_obj):
+        with self._lock:  # whichever of the main thread and the watchdog gets here first
+            if self._emitted:
+                return
+            self._emitted = True
+            if self.rank == 0 and self.line is not None:
+                self.line["train_step"] = train_obj
+                print(json.dumps(self.line), flush=True)
+
+    def fail(self, msg, code):
+        self.emit({"error": msg})
+        sys.stdout.flush()
+        sys.stderr.write(f"bench.py: rank {self.rank}: {msg}\n")
+        sys.stderr.flush()
+        os._exit(code)
+
+    def start_watchdog(self, timeout_s):
+        def run():
+            if not self._done.wait(timeout_s):
+                self.fail("the training-step section did not finish in time (a rank or a collective hung); headline unaffected", 3)
+        threading.Thread(target=run, daemon=True).start()
+
+    def finish(self):
+        self._done.set()
+
+
 def plumbing_check(args, rank, world):
     """EEC_BENCH_PLUMBING=1 (host tests, no GPU): the N > 1 control flow only -- rendezvous, barrier, the loss all-reduce
     through parallel.combine_exit_losses, max-over-ranks timing, rank 0's one JSON line -- over gloo on CPU tensors."""
@@ -109,9 +146,23 @@ def plumbing_check(args, rank, world):
     if world > 1:
         dist.barrier()
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        print(json.dumps({"plumbing": True, "n_gpus": world, "steps": args.steps, "combined": combined.tolist(),
-                          "max_rank_seconds": float(dt.item())}), flush=True)
+    line = {"plumbing": True, "n_gpus": world, "steps": args.steps, "combined": combined.tolist(),
+            "max_rank_seconds": float(dt.item())} if rank == 0 else None
+    # the guarded last section, as in the real run: EEC_BENCH_FAIL_STEP_RANK makes that rank fail INSIDE a step, i.e. before
+    # the step's collectives, which its peers then wait in for ever -- until the launcher has seen the non-zero status
+    guard = RecordGuard(rank, line)
+    guard.start_watchdog(float(os.environ.get("EEC_BENCH_TRAIN_TIMEOUT", "240")))
+    try:
+        if os.environ.get("EEC_BENCH_FAIL_STEP_RANK") == str(rank):
+            raise RuntimeError("injected failure inside a training step")
+        if world > 1 and os.environ.get("EEC_BENCH_FAIL_STEP_RANK") is not None:
+            dist.all_reduce(torch.zeros(1))  # the collective of a step the failed rank never reaches
+    except Exception as e:
+        if world > 1:
+            guard.fail(f"{type(e).__name__}: {e}", 4)
+        raise
+    guard.finish()
+    guard.emit("ok")
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -240,6 +291,35 @@ def main():
         d = time.perf_counter() - t1
         forward_only = {"value": round(B * T * args.steps / d, 1), "ms_per_step": round(d / args.steps * 1e3, 4)}
 
+    # ---- parity against the committed golden fixtures (tests/golden/*.npz: produced by the reference's own class body in the
+    # build container, make_golden.py), measured in this run for the mode that is timed: the default 12-layer model on
+    # B = 4, T = 1027 with random-init heads (near-uniform outputs) and with heads x8 (peaky, trained-like outputs) ----
+    parity = None
+    if rank == 0 and world == 1:
+        import numpy as np
+        parity = {"policy": "|dlogp| <= tol * max(1, max|logp| / 8): the operand rounding of a mode is a RELATIVE error of the "
+                            "logits, so near-uniform outputs (max|logp| <= 8) are held to the flat tolerance and peaky ones to the "
+                            "same bound relative to their scale (tests/test_gpu_parity.py::logp_tolerance)",
+                  "tol": {"f16f8": 1e-3, "f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}[args.precision], "fixtures": {}}
+        for name in ("config1", "config1_peaky"):
+            z = np.load(os.path.join(ROOT, "tests", "golden", f"{name}.npz"))
+            pm = Early_conformer(device=dev, **CFG).eval()
+            pm.load_state_dict(synth.synth_state_dict(pm.state_dict(), seed=int(z["seed"]), style=str(z["style"]),
+                                                      head_scale=float(z["head_scale"])))
+            pm = pm.to(dev)
+            pm.precision = args.precision
+            with torch.no_grad():
+                got = pm(synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"])).to(dev), torch.from_numpy(z["lengths"]))
+            err = np.abs(got[:, :, ::int(z["stride"])].cpu().numpy() - z["logp"])
+            top = z["logp"] >= -10.0  # the entries a decoder reads
+            parity["fixtures"][name] = {"max_abs_logp": round(float(np.abs(z["logp"]).max()), 2), "max_err": float(f"{err.max():.3e}"),
+                                        "max_err_where_logp_ge_minus10": float(f"{err[top].max():.3e}"),
+                                        "within_flat_tol": bool(err.max() < parity["tol"]),
+                                        "within_policy": bool(err.max() < parity["tol"] * max(1.0, float(np.abs(z["logp"]).max()) / 8.0))}
+            del pm
+        parity["reference_fp32_noise"] = ("the reference's own fp32 forward differs from an fp64 evaluation of itself by 3.5e-6 "
+                                          "(config1) / 3.9e-5 (config1_peaky) max |dlogp| on the CPU: the same 11x growth with the logit scale")
+
     # ---- training step (secondary lines; BASELINE.json configs[3] on every rank, configs[2] geometry at N = 1) ----
     # one step = train.py:53-70: forward in train mode (dropout 0.1, batch-statistics BatchNorm), summed per-exit CTC loss,
     # backward (HIP training kernels), gradient all-reduce over the ranks (bucketed RCCL, N > 1), clip_grad_norm_, AdamW.
@@ -252,11 +332,15 @@ def main():
         opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
         torch.manual_seed(rank)
 
+        # gradients live in flat per-exit-group buckets; with N > 1 each bucket's RCCL all-reduce starts as the backward
+        # finishes that exit group (eec_train_backward_ex) and runs under the backward of the earlier groups
+        tm.enable_data_parallel(B)
+
         def step():
             opt.zero_grad(set_to_none=True)
             loss = exit_ctc_losses(tm(mel, lengths), tgt, tgt_len).sum()
             loss.backward()
-            parallel.allreduce_gradients(params, B)
+            tm.sync_gradients()
             torch.nn.utils.clip_grad_norm_(params, 1.0)
             opt.step()
             return loss
@@ -274,8 +358,13 @@ def main():
             d = (time.perf_counter() - t1) / n_steps
             if not torch.isfinite(loss).item():
                 err = "non-finite loss"
-        except Exception as e:  # reported, and every rank still reaches the collective below
+        except Exception as e:
             err = f"{type(e).__name__}: {e}"[:300]
+            if dist is not None:
+                # a rank that failed inside a step has skipped collectives its peers are waiting in: nothing sensible can be
+                # exchanged any more.  Emit the record (rank 0), then leave with a non-zero status -- the launcher (or torchrun)
+                # tears the other ranks down and the job is recorded as failed, never as rc 0.
+                fail_section(f"{label}: {err}", 4)
         if dist is not None:
             t = torch.tensor([d if not err else float("inf")], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -495,13 +584,14 @@ def main():
             "metric": "mel-frames/sec encoder forward (all exits) + summed per-exit CTC loss, d_model=256 12-layer",
             "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"f16f8": "fp16 + 2x fp8-correction MFMA in the feed-forward, fp16x3 elsewhere, fp32 accumulate",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"f16f8": "fp16 + 2x fp8-correction MFMA (feed-forward, projections), fp16x3 exit heads and stem, fp32 accumulate",
                                                              "f16x3": "fp16x3 (hi/lo-split fp16 MFMA operands, fp32 accumulate)",
                                                              "mixed": "fp16 FFN + fp16x3 projections", "f16": "fp16"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"early_conformer ctc 12-layer d_model=256 (6 exits x 2), batch {B}/GPU, mel [80 x {T}] -> T'={Tq}, log-normal synthetic mel, random-init weights (BASELINE.json configs[1])",
                        "global_batch": B * world, "mel_frames": T, "parallelism": f"dp{world} (utterance-batch shards)",
-                       "precision_mode": args.precision, "parity_tolerance_logp": {"f16f8": 1e-3, "f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}[args.precision]},
+                       "precision_mode": args.precision},
+            "parity": parity,
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),
             "roofline": roofline, "cpu_baseline": cpu, "forward_only": forward_only, "kernel_time": kernel_ms,
@@ -513,27 +603,11 @@ def main():
 
     # ---- training-step lines LAST, under a watchdog: every other number of the record is complete by now, and a collective
     # that never returns on some rank (N > 1) must not take the headline line down with it ----
-    emit_lock, emitted = threading.Lock(), []
-
-    def emit(train_obj):
-        with emit_lock:  # exactly one record, whichever of the main thread and the watchdog gets here first
-            if emitted:
-                return
-            emitted.append(True)
-            if rank == 0:
-                line["train_step"] = train_obj
-                print(json.dumps(line), flush=True)
-
-    done = threading.Event()
-
-    def watchdog():
-        if not done.wait(float(os.environ.get("EEC_BENCH_TRAIN_TIMEOUT", "240"))):
-            emit({"error": "the training-step section did not finish in time (a rank or a collective hung); headline unaffected"})
-            sys.stdout.flush()
-            os._exit(0)
+    guard = RecordGuard(rank, line)
+    emit, fail_section = guard.emit, guard.fail
 
     if not args.no_modes and not args.no_train:
-        threading.Thread(target=watchdog, daemon=True).start()
+        guard.start_watchdog(float(os.environ.get("EEC_BENCH_TRAIN_TIMEOUT", "240")))
         n_tr = max(3, args.steps // 10)
         lab4 = (f"CTC training step, default 12-layer d_model=256, batch {B}/GPU x {world} GPU(s), mel [80 x {T}] "
                 "(BASELINE.json configs[3]; gradients all-reduced in 64 MB buckets when N > 1)")
@@ -546,7 +620,7 @@ def main():
         if rank == 0:
             train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3}
 
-        done.set()
+        guard.finish()
         emit(train if rank == 0 else None)
     else:
         emit(None)

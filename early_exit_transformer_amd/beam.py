@@ -38,6 +38,18 @@ def sequence_length_penalty(length: int, alpha: float = 0.6) -> float:
     return ((5 + length) / (5 + 1)) ** alpha
 
 
+class CTCHypothesis:
+    """One CTC beam-search hypothesis, with the attribute names of torchaudio's ``CUCTCHypothesis`` (tokens: List[int] without
+    blanks / repeats, words: List[str] -- empty here, as for a lexicon-free decoder --, score: float)."""
+    __slots__ = ("tokens", "words", "score")
+
+    def __init__(self, tokens, words, score):
+        self.tokens, self.words, self.score = tokens, words, score
+
+    def __repr__(self):
+        return f"CTCHypothesis(tokens={self.tokens}, words={self.words}, score={self.score:.4f})"
+
+
 class BeamInference:
     """``args`` needs ``dec_voc_size, trg_sos_idx, trg_eos_idx, trg_pad_idx, beam_size, pen_alpha, device`` (the fields
     util/conf.py:455-486 injects); every one of them can also be given per call, as in the reference."""
@@ -47,14 +59,16 @@ class BeamInference:
 
     sequence_length_penalty = staticmethod(sequence_length_penalty)
 
-    def ctc_cuda_predict(self, emission: Tensor, tokens=None, beam_size: Optional[int] = None) -> List[List[int]]:
-        """util/beam_infer.py:102-112: beam-search hypotheses (token ids, nbest = 1) of one exit's log-probs
-        ``emission`` [B, T', V], input length T' for every utterance, beam ``args.beam_size``, blank_skip_threshold 0.95.
-        ``tokens`` (the token file the torchaudio decoder takes) is accepted and unused: ids are returned, blank = 0."""
+    def ctc_cuda_predict(self, emission: Tensor, tokens=None, beam_size: Optional[int] = None) -> List[List["CTCHypothesis"]]:
+        """util/beam_infer.py:102-112: the nbest (= 1) beam-search hypotheses of one exit's log-probs ``emission`` [B, T', V],
+        input length T' for every utterance, beam ``args.beam_size``, blank_skip_threshold 0.95 -- per utterance a list of
+        hypothesis objects with ``.tokens`` / ``.words`` / ``.score`` like torchaudio's, so the reference's call sites
+        (``best[0][0].tokens`` train.py:82, ``best_[0].tokens`` inference.py:70) work unchanged.  ``tokens`` (the token file
+        the torchaudio decoder takes) is accepted and unused: ids are returned, blank = 0."""
         beam = self._arg(beam_size, "beam_size")
-        tok, cnt, _ = ctc_beam_decode(emission, beam_size=beam, blank=0, blank_skip_threshold=0.95)
-        tok, cnt = tok.cpu(), cnt.cpu()
-        return [tok[b, : int(cnt[b])].tolist() for b in range(tok.size(0))]
+        tok, cnt, score = ctc_beam_decode(emission, beam_size=beam, blank=0, blank_skip_threshold=0.95)
+        tok, cnt, score = tok.cpu(), cnt.cpu(), score.cpu()
+        return [[CTCHypothesis(tok[b, : int(cnt[b])].tolist(), [], float(score[b]))] for b in range(tok.size(0))]
 
     def _arg(self, value, name):
         if value is not None:

@@ -77,16 +77,19 @@ class EecDecoderParams(C.Structure):
                 ("max_len", C.c_int32), ("norm_w", C.c_void_p), ("norm_b", C.c_void_p), ("head_w", C.c_void_p), ("head_b", C.c_void_p)]
 
 
+# host callback of eec_train_backward_ex: (exit group just finished, or -1 after the stem; user pointer)
+GROUP_DONE_FN = C.CFUNCTYPE(None, C.c_int, C.c_void_p)
+
 EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_create", "eec_encoder_destroy",
            "eec_encoder_pack", "eec_encoder_workspace_bytes", "eec_encoder_forward", "eec_greedy_ctc",
            "eec_encoder_set_profiling", "eec_encoder_profile_read", "eec_ctc_loss", "eec_encoder_pack_legacy",
            "eec_encoder_forward_prefix", "eec_encoder_group_workspace_bytes", "eec_encoder_group_forward",
            "eec_encoder_head_forward", "eec_encoder_stem1_forward", "eec_encoder_lengths",
            "eec_ctc_backward_workspace_bytes", "eec_ctc_loss_forward", "eec_ctc_loss_backward", "eec_logsoftmax_backward",
-           "eec_ctc_beam_workspace_bytes", "eec_ctc_beam_decode",
+           "eec_ctc_beam_workspace_bytes", "eec_ctc_beam_decode", "eec_ctc_beam_decode_ex",
            "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward",
            "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
-           "eec_train_forward", "eec_train_backward", "eec_train_gemm",
+           "eec_train_forward", "eec_train_backward", "eec_train_backward_ex", "eec_train_gemm",
            "eec_decoder_last_error", "eec_decoder_workspace_bytes", "eec_decoder_forward",
            "eec_decoder_step_last_error", "eec_decoder_step_max_beams", "eec_decoder_cache_bytes", "eec_decoder_begin", "eec_decoder_step", "eec_decoder_step_multi", "eec_upload_i64_max", "eec_upload_i64", "eec_beam_select"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
@@ -140,6 +143,8 @@ def load() -> C.CDLL:
     lib.eec_ctc_beam_workspace_bytes.restype = C.c_size_t
     lib.eec_ctc_beam_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.eec_ctc_beam_decode_ex.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_frontend_last_error.restype = C.c_char_p
     lib.eec_frontend_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     lib.eec_frontend_destroy.argtypes = [C.c_void_p]
@@ -156,6 +161,8 @@ def load() -> C.CDLL:
                                       C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_train_backward.argtypes = [C.c_void_p, C.POINTER(EecParams), C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_backward_ex.argtypes = [C.c_void_p, C.POINTER(EecParams), C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, GROUP_DONE_FN, C.c_void_p]
     lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
     lib.eec_decoder_last_error.restype = C.c_char_p

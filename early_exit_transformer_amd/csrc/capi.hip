@@ -509,14 +509,15 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   hipStream_t st = (hipStream_t)stream;
   const int np_ffn = precision == EEC_PREC_F16X3 ? 3 : (precision == EEC_PREC_F16F8 ? 8 : 1);
   const int np_o = precision == EEC_PREC_F16 ? 1 : 3;
-  // f16f8 (default): besides the feed-forward, out_proj + pointwise-1 and pointwise-2 run on the f8 stream
-  // (fp16 + two fp8 correction products); in_proj (its error is amplified by the softmax) and the exit heads (their
-  // error is the logit error) keep the exact 3-pass split.  Measured on the default model, 3 weight / input seeds
-  // (profiles/r02_np_budget.txt): max |dlogp| 2.5e-4; with in_proj on f8 as well 3.6e-4, heads too 4.0e-4
+  // f16f8 (default): besides the feed-forward, out_proj + pointwise-1, pointwise-2 and (round 3) in_proj run on the f8
+  // stream (fp16 + two fp8 correction products); the exit heads (their error is the logit error) keep the exact 3-pass
+  // split.  Measured on the default model, 3 weight / input seeds (profiles/r02_np_budget.txt): max |dlogp| 3.6e-4 (2.5e-4
+  // with in_proj on the 3-pass split: its error is amplified by the softmax, but the chain kernel's in_proj tail is
+  // MFMA-bound at three passes: -8 us of 169 per launch, profiles/r03_ab_chain_knobs.txt), heads too 4.0e-4
   // (d_model 512 keeps the fragment formats there: its f8 projection kernels do not fit the register file yet)
   const int np_p = (precision == EEC_PREC_F16F8 && c.arch == EEC_ARCH_CONFORMER && c.d_model == 256 && c.d_ff % 128 == 0) ? 8 : np_o;
   // operand format per GEMM group of the production plan (a diagnostic build can override them one by one)
-  int np_qkv = np_o, np_att = np_o, np_glu = np_p, np_front = np_p, np_head = np_o;
+  int np_qkv = np_p, np_att = np_o, np_glu = np_p, np_front = np_p, np_head = np_o;
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * c.d_model : nullptr;  // V keeps its fp16 residual in the split modes
 #ifdef EEC_NP_EXPERIMENT
   if (const char* ov = getenv("EEC_NP_OVERRIDE")) {  // e.g. "qkv=1,glu=1": error-budget experiments (tools/np_budget.py)
@@ -625,7 +626,7 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (done()) return finish_dbg();
       {
         QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo, L.attn_in_f8};
-        TIMED(KC_QKV, launch_qkv(a, np_o, st));
+        TIMED(KC_QKV, launch_qkv(a, np_qkv, st));
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
         ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
@@ -733,7 +734,7 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
   const LayerBufs bufs{x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, key_len};
   const int np_p = (precision == EEC_PREC_F16F8 && c.d_model == 256 && c.d_ff % 128 == 0) ? 8 : np_o;
-  const LayerFormats nps{np_ffn, np_p, np_o, np_o, np_p};  // {ffn, front, qkv, att, glu}
+  const LayerFormats nps{np_ffn, np_p, np_p, np_o, np_p};  // {ffn, front, qkv, att, glu}
   const int l0 = group * c.layers_per_exit;
   return run_layer_plan(enc, l0, l0 + c.layers_per_exit, bufs, B, Tq, nps, [](int) -> float* { return nullptr; }, st);
 }

@@ -41,7 +41,7 @@ __device__ __forceinline__ unsigned long long cb_mix(unsigned long long h, int c
 }
 
 __global__ __launch_bounds__(kCbThreads) void ctc_beam_kernel(const float* __restrict__ logp, int Tq, int V, int blank, int beam,
-                                                              float log_thr, int* __restrict__ backptr, int* __restrict__ tokens,
+                                                              float log_thr, int skip_drops, int* __restrict__ backptr, int* __restrict__ tokens,
                                                               int* __restrict__ counts, float* __restrict__ scores) {
   __shared__ CbBeam bufs[2][kCbMaxBeam];
   __shared__ float tot[kCbMaxBeam], stay_pb[kCbMaxBeam], stay_pnb[kCbMaxBeam], row[256];
@@ -66,9 +66,11 @@ __global__ __launch_bounds__(kCbThreads) void ctc_beam_kernel(const float* __res
     row[c] = lpc;
     __syncthreads();
     const float lpb = row[blank];
-    if (lpb > log_thr) {  // blank frame, not expanded: all mass ends in blank
+    if (lpb > log_thr) {  // blank-dominated frame, not expanded
       if (c < nb) {
-        N[c] = CbBeam{cb_lae(B[c].pb, B[c].pnb) + lpb, -INFINITY, B[c].last, B[c].len, B[c].hash};
+        // skip_drops == 0: the frame counts as a blank frame (all mass ends in blank: a label repeated across it stays a repeat)
+        // skip_drops != 0: the frame is DROPPED, as if the sequence were one frame shorter (the repeat collapses)
+        N[c] = skip_drops ? B[c] : CbBeam{cb_lae(B[c].pb, B[c].pnb) + lpb, -INFINITY, B[c].last, B[c].len, B[c].hash};
         bp[t * kCbMaxBeam + c] = c << 16;
       }
       __syncthreads();
@@ -189,12 +191,12 @@ __global__ __launch_bounds__(kCbThreads) void ctc_beam_kernel(const float* __res
   }
 }
 
-hipError_t launch_ctc_beam(const float* logp, int n_seq, int Tq, int V, int blank, int beam, float blank_skip_threshold, int* backptr,
-                           int* tokens, int* counts, float* scores, hipStream_t st) {
+hipError_t launch_ctc_beam(const float* logp, int n_seq, int Tq, int V, int blank, int beam, float blank_skip_threshold, int skip_drops,
+                           int* backptr, int* tokens, int* counts, float* scores, hipStream_t st) {
   if (V < 1 || V > 256 || beam < 1 || beam > kCbMaxBeam || blank < 0 || blank >= V) return hipErrorInvalidValue;
   const float log_thr = (blank_skip_threshold > 0.f && blank_skip_threshold < 1.f) ? logf(blank_skip_threshold) : INFINITY;
-  hipLaunchKernelGGL(ctc_beam_kernel, dim3(n_seq), dim3(kCbThreads), 0, st, logp, Tq, V, blank, beam, log_thr, backptr, tokens, counts,
-                     scores);
+  hipLaunchKernelGGL(ctc_beam_kernel, dim3(n_seq), dim3(kCbThreads), 0, st, logp, Tq, V, blank, beam, log_thr, skip_drops, backptr, tokens,
+                     counts, scores);
   return hipGetLastError();
 }
 
@@ -208,10 +210,15 @@ size_t eec_ctc_beam_workspace_bytes(int n_seq, int Tq) {
 
 int eec_ctc_beam_decode(const float* logp, int n_seq, int Tq, int V, int blank, int beam_size, float blank_skip_threshold,
                         void* workspace, int32_t* tokens, int32_t* counts, float* scores, void* stream) {
+  return eec_ctc_beam_decode_ex(logp, n_seq, Tq, V, blank, beam_size, blank_skip_threshold, 0, workspace, tokens, counts, scores, stream);
+}
+
+int eec_ctc_beam_decode_ex(const float* logp, int n_seq, int Tq, int V, int blank, int beam_size, float blank_skip_threshold,
+                           int skip_drops_frame, void* workspace, int32_t* tokens, int32_t* counts, float* scores, void* stream) {
   if (!logp || !workspace || !tokens || !counts || !scores || n_seq <= 0 || Tq <= 0) return EEC_ERR_BAD_ARG;
   if (V < 1 || V > 256 || beam_size < 1 || beam_size > eec::kCbMaxBeam || blank < 0 || blank >= V) return EEC_ERR_UNSUPPORTED;
-  return (int)eec::launch_ctc_beam(logp, n_seq, Tq, V, blank, beam_size, blank_skip_threshold, (int*)workspace, tokens, counts, scores,
-                                   (hipStream_t)stream);
+  return (int)eec::launch_ctc_beam(logp, n_seq, Tq, V, blank, beam_size, blank_skip_threshold, skip_drops_frame != 0, (int*)workspace, tokens,
+                                   counts, scores, (hipStream_t)stream);
 }
 
 }  // extern "C"

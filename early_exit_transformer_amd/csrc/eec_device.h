@@ -184,6 +184,18 @@ __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (
 #ifdef EEC_KSTEP_STAMPS
 __device__ void eec_kstep_stamp();
 #endif
+// weight-stream load (experiment knob EEC_W_NT: non-temporal = L1-bypassing loads for the streamed fragments)
+#ifndef EEC_W_NT
+#define EEC_W_NT 0
+#endif
+__device__ __forceinline__ uint4 wload(const uint4* p) {
+#if EEC_W_NT
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(uint4, __builtin_nontemporal_load((const u32x4_t*)p));
+#else
+  return *p;
+#endif
+}
 template <int NP, int PF, int NT = 1>
 struct WRing {
   uint4 q[PF][NT][(NP == 3) ? 2 : 1];
@@ -416,11 +428,11 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const uint4* r = rec_lane + nt * nt_stride - lane_id();
-    g.lo[nt][0] = r[256 + 2 * lane_id()];
+    g.lo[nt][0] = wload(r + 256 + 2 * lane_id());
 #ifdef EEC_LO_HALF  // timing-only build: half the residual bytes (what an fp4 residual would stream)
     g.lo[nt][1] = g.lo[nt][0];
 #else
-    g.lo[nt][1] = r[256 + 2 * lane_id() + 1];
+    g.lo[nt][1] = wload(r + 256 + 2 * lane_id() + 1);
 #endif
     g.sc[nt] = ((const int*)(r + 384))[lane_id()];
   }
@@ -491,11 +503,11 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
     if (s + PF < KS) {
 #endif
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = rec_lane[nt * nt_stride + hi_addr(s + PF)];
+      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = wload(rec_lane + nt * nt_stride + hi_addr(s + PF));
     } else if (CONT && next_lane) {
 #ifndef EEC_ABLATE_W
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = next_lane[nt * nt_stride + hi_addr(s + PF - KS)];
+      for (int nt = 0; nt < NT; ++nt) r.q[s % PF][nt][0] = wload(next_lane + nt * nt_stride + hi_addr(s + PF - KS));
 #endif
     }
     if (q == 3) {  // the group's two correction products
@@ -544,7 +556,7 @@ __device__ __forceinline__ void ring_fill_f8(WRing<1, PF, NT>& r, const uint4* _
 #pragma unroll
   for (int p = 0; p < PF; ++p)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) r.q[p][nt][0] = rec_lane[nt * nt_stride + (size_t)(p >> 2) * kF8Rec + (size_t)(p & 3) * 64];
+    for (int nt = 0; nt < NT; ++nt) r.q[p][nt][0] = wload(rec_lane + nt * nt_stride + (size_t)(p >> 2) * kF8Rec + (size_t)(p & 3) * 64);
   __builtin_amdgcn_sched_barrier(0);
 }
 

@@ -121,6 +121,43 @@ __device__ __forceinline__ unsigned touch_share(const void* base, size_t bytes, 
   const size_t ln = ((blockIdx.x >> 3) & 31) * per_wg + wl * per_wave + k;
   return (k < per_wave && ln < n_lines) ? *(const unsigned*)((const char*)base + ln * 128) : 0u;
 }
+// Rolling L2 prefetch inside a stage (f8 stream, d_model 256): the stage's weights (6.5 MB) exceed an XCD's L2 (4 MB), so
+// behind the first 4 MB every line's first reader pays the trip to the Infinity Cache and the 32 CUs of the XCD, walking the
+// same stream in near lockstep, all wait on that one fill.  Each slot, ONE wave per workgroup touches (one dword per 128-B
+// line) the workgroup's 1/32 share of the W1 + W2 records of the chunk EEC_ROLL_WARM slots ahead: 1600 lines per chunk,
+// 50 per workgroup = one wave-instruction.
+#ifndef EEC_ROLL_WARM
+#define EEC_ROLL_WARM 0
+#endif
+template <int D>
+__device__ __forceinline__ unsigned touch_chunk(const uint4* w1f8, const uint4* w2f8, int c, int F, int lane) {
+  constexpr int kRecLines = kF8Rec * 16 / 128;                 // 50 lines per record
+  constexpr int n1 = 4 * (D / 64) * kRecLines;                 // W1: 4 hidden tiles x D/64 records, contiguous
+  constexpr int n2 = 2 * kRecLines;                            // W2: per n-tile 2 records
+  constexpr int total = n1 + (D / 32) * n2, per_wg = (total + 31) / 32;
+  static_assert(per_wg <= 64, "one wave-instruction per workgroup and chunk");
+  const int li = (int)((blockIdx.x >> 3) & 31) * per_wg + lane;
+  if (lane >= per_wg || li >= total) return 0u;
+  const char* p;
+  if (li < n1) {
+    p = (const char*)(w1f8 + (size_t)(4 * c) * (D / 64) * kF8Rec) + (size_t)li * 128;
+  } else {
+    const int t = li - n1, nt = t / n2, r = t - nt * n2;
+    p = (const char*)(w2f8 + ((size_t)nt * (F / 64) + 2 * c) * kF8Rec) + (size_t)r * 128;
+  }
+#if defined(EEC_ROLL_WARM_DMA)
+  // no register destination: the dword lands in 256 dead bytes of LDS (m0 = LDS byte address, + 4 * lane), so nothing stays
+  // live across the slot; m0 is saved and restored around the instruction
+  {
+    unsigned m0_save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(m0_save) : "v"(p), "s"(EEC_ROLL_WARM_DMA) : "memory");
+  }
+  return 0u;
+#else
+  return *(const unsigned*)p;
+#endif
+}
 // f(IntTag<0>{}), ..., f(IntTag<N-1>{}) for N <= 2: a stage loop whose index is a compile-time constant
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -456,6 +493,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
 #if EEC_WARM_SLOTS > 0
       unsigned warm[4] = {0u, 0u, 0u, 0u};
 #endif
+#if EEC_ROLL_WARM > 0
+      unsigned roll_prev = 0u;
+#endif
       for (int s = 0; s < nslots; ++s) {
 #if EEC_WARM_SLOTS > 0
         if (s == nslots - EEC_WARM_SLOTS) {
@@ -475,6 +515,13 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
             warm[0] = QNP == 8 ? touch_share(a.qkv.wf8, (size_t)(3 * D / 32) * (D / 64) * kF8Rec * 16, wl_s, 0, lane_t)
                                : touch_share(a.qkv.wp, (size_t)3 * D * D * 2 * (QNP == 3 ? 2 : 1), wl_s, 0, lane_t);
           }
+        }
+#endif
+#if EEC_ROLL_WARM > 0
+        if constexpr (NP == 8 && D == 256) {
+          sink ^= roll_prev;  // the touch of the previous slot (long complete): keeps exactly one result register live
+          roll_prev = 0u;
+          if (wl_s == 0 && s + EEC_ROLL_WARM < nchunk) roll_prev = touch_chunk<D>(W.w1f8, W.w2f8, phys(s + EEC_ROLL_WARM), F, lane);
         }
 #endif
         if (s >= 2) {
@@ -506,6 +553,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
       }
 #if EEC_WARM_SLOTS > 0
       sink ^= warm[0] ^ warm[1] ^ warm[2] ^ warm[3];
+#endif
+#if EEC_ROLL_WARM > 0
+      sink ^= roll_prev;
 #endif
     }
     // ---- stage epilogue ----
@@ -619,21 +669,24 @@ hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_f
 #endif
   const int f = front ? np_front : 0, q = tail ? np_tail : 0;
 #ifdef EEC_CHAIN_MINIMAL  // tuning builds: only the three launches of the default (f16f8) production plan
-  if (np == 8 && f == 0 && q == 3 && a.nstage == 1) return launch_chain_t<D, 8, 0, 0, 3, 1>(a, st);
-  if (np == 8 && f == 8 && q == 3 && a.nstage == 2) return launch_chain_t<D, 8, 0, 8, 3, 2>(a, st);
+  if (np == 8 && f == 0 && q == 8 && a.nstage == 1) return launch_chain_t<D, 8, 0, 0, 8, 1>(a, st);
+  if (np == 8 && f == 8 && q == 8 && a.nstage == 2) return launch_chain_t<D, 8, 0, 8, 8, 2>(a, st);
   if (np == 8 && f == 8 && q == 0 && a.nstage == 1) return launch_chain_t<D, 8, 0, 8, 0, 1>(a, st);
   return hipErrorInvalidValue;
 #else
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \
   if (np == NP_ && f == F_ && q == Q_)                                                                   \
     return a.nstage == 2 ? launch_chain_t<D, NP_, 0, F_, Q_, 2>(a, st) : launch_chain_t<D, NP_, 0, F_, Q_, 1>(a, st);
-  EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 8, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 8, 3)  // f16f8 at d_model 256
-  EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 3, 3)                                                  // ... and at d_model 512
+  if constexpr (D == 256) {  // f16f8 at d_model 256: conv front and in_proj tail on the f8 stream too
+    EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 8, 0) EEC_CHAIN_CASE(8, 0, 8) EEC_CHAIN_CASE(8, 8, 8)
+  } else {  // ... at d_model 512 they keep the fragment formats
+    EEC_CHAIN_CASE(8, 0, 0) EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 3, 3)
+  }
   EEC_CHAIN_CASE(3, 0, 0) EEC_CHAIN_CASE(3, 3, 0) EEC_CHAIN_CASE(3, 0, 3) EEC_CHAIN_CASE(3, 3, 3)
   EEC_CHAIN_CASE(1, 0, 0) EEC_CHAIN_CASE(1, 3, 0) EEC_CHAIN_CASE(1, 0, 3) EEC_CHAIN_CASE(1, 3, 3)
   EEC_CHAIN_CASE(1, 1, 0) EEC_CHAIN_CASE(1, 0, 1) EEC_CHAIN_CASE(1, 1, 1)
 #ifdef EEC_NP_EXPERIMENT  // diagnostic build: independent operand formats for the conv front and the in_proj tail
-  EEC_CHAIN_CASE(8, 1, 0) EEC_CHAIN_CASE(8, 0, 1) EEC_CHAIN_CASE(8, 1, 1) EEC_CHAIN_CASE(8, 3, 8) EEC_CHAIN_CASE(8, 0, 8) EEC_CHAIN_CASE(8, 8, 8)
+  EEC_CHAIN_CASE(8, 1, 0) EEC_CHAIN_CASE(8, 0, 1) EEC_CHAIN_CASE(8, 1, 1) EEC_CHAIN_CASE(8, 3, 8) EEC_CHAIN_CASE(8, 0, 3) EEC_CHAIN_CASE(8, 8, 3) EEC_CHAIN_CASE(8, 3, 0) EEC_CHAIN_CASE(8, 3, 3)
 #endif
 #undef EEC_CHAIN_CASE
   return hipErrorInvalidValue;

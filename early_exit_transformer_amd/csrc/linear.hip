@@ -261,13 +261,16 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   };
   Blk fa, fb;
   if (nkt > 0) fetch(fa, 0);
+  EEC_TL_STAMP(glu, 11);
   for (int kt0 = 0; kt0 < nkt; kt0 += 2 * KB) {
     if (kt0 + KB < nkt) fetch(fb, kt0 + KB);
     block(fa, kt0);
+    EEC_TL_STAMP(glu, kt0 == 0 ? 12 : 14);
     if (kt0 + KB < nkt) {
       if (kt0 + 2 * KB < nkt) fetch(fa, kt0 + 2 * KB);
       block(fb, kt0 + KB);
     }
+    EEC_TL_STAMP(glu, kt0 == 0 ? 13 : 15);
   }
   // normalise and write the planes.  No valid key at all (length 0): the installed torch returns zeros ("safe softmax").
 #pragma unroll

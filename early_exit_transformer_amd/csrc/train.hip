@@ -421,7 +421,8 @@ void conv_bwd(Run& r, const ConvTape& t, float* dx, const eec_layer_params& L, e
   ln_bwd(r, dln, t.x, L.conv_ln_w, t.mean, t.rstd, dx, true, (float*)G.conv_ln_w, (float*)G.conv_ln_b, M, D);
 }
 
-void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out, const float* grad_taps) {
+void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* out, const float* grad_out, const float* grad_taps,
+              eec_group_done_fn on_group = nullptr, void* user = nullptr) {
   eec_trainer* tr = r.tr;
   const eec_config& c = tr->cfg;
   const int B = tr->B, T1 = tr->T1, Tq = tr->Tq, M = tr->M, D = c.d_model, C = c.n_mels, V = c.vocab;
@@ -447,6 +448,13 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
       attn_bwd(r, t.at, dx, L, G);
       ffn_bwd(r, t.f1, dx, L.ffn1_ln_w, L.ffn1_w1, L.ffn1_w2, (float*)G.ffn1_ln_w, (float*)G.ffn1_ln_b, (float*)G.ffn1_w1, (float*)G.ffn1_b1,
               (float*)G.ffn1_w2, (float*)G.ffn1_b2);
+    }
+    if (on_group && !r.dry) {
+      // every gradient of exit group e (its layers and its head) is now enqueued; the weight-gradient jobs of the side
+      // stream are joined first (the join the next group's scratch reset would make anyway), so "after everything on the
+      // main stream so far" is a sufficient dependency for the caller's collective
+      join_side(r);
+      on_group(e, user);
     }
   }
   // stem
@@ -478,13 +486,17 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
   RUN(launch_col2im_stride2(Gc, dout1, B, T1, Tq, D, r.st));
   linear_bwd_weight(r, dout1, tr->a1, (float*)Gp->sub0_w, (float*)Gp->sub0_b, B * T1, D, 3 * C);
   join_side(r);  // every gradient is complete in main-stream order
+  if (on_group && !r.dry) on_group(-1, user);
 }
 
 int check_trainer_cfg(const eec_config& c) {
   if (c.arch != EEC_ARCH_CONFORMER) return tfail(EEC_ERR_UNSUPPORTED, "the training step covers the Conformer architecture");
   if (c.d_model <= 0 || c.d_model > 1024 || c.n_heads <= 0 || c.d_model % c.n_heads) return tfail(EEC_ERR_BAD_ARG, "d_model <= 1024, divisible by n_heads");
   if (c.dw_kernel < 1 || c.dw_kernel > 31 || !(c.dw_kernel & 1)) return tfail(EEC_ERR_BAD_ARG, "depthwise kernel: odd, <= 31");
-  if (c.d_ff <= 0 || c.n_exits <= 0 || c.layers_per_exit <= 0 || c.n_mels <= 0 || c.vocab <= 0 || c.vocab > 1024) return tfail(EEC_ERR_BAD_ARG, "bad configuration");
+  if (c.d_ff <= 0 || c.n_exits <= 0 || c.layers_per_exit <= 0 || c.n_mels <= 0 || c.vocab <= 0) return tfail(EEC_ERR_BAD_ARG, "bad configuration");
+  // the log-softmax backward and the CTC gradient hold a vocabulary row in one wave (csrc/ctc.hip): refuse here, before a
+  // forward has recorded a multi-GB tape that loss.backward() could not use
+  if (c.vocab > 256 || c.vocab % 4) return tfail(EEC_ERR_UNSUPPORTED, "the training step needs vocab <= 256 and a multiple of 4 (got " + std::to_string(c.vocab) + ")");
   return 0;
 }
 
@@ -575,6 +587,12 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
 
 int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
                        const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream) {
+  return eec_train_backward_ex(tr, params, grads, out, grad_out, grad_taps, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+int eec_train_backward_ex(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
+                          const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream, eec_group_done_fn on_group,
+                          void* user) {
   if (!tr || !params || !grads || !out || !grad_out || !workspace) return tfail(EEC_ERR_BAD_ARG, "null argument");
   if (!tr->recorded) return tfail(EEC_ERR_BAD_ARG, "no recorded forward (eec_train_forward first, same workspace)");
   int dev = -1;
@@ -611,7 +629,7 @@ int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_para
   r.sscr.base = (char*)workspace + tr->tape_bytes + dx_bytes, r.sscr.cap = side_bytes;
   r.scr.base = (char*)workspace + tr->tape_bytes + dx_bytes + side_bytes;
   r.tape.cap = dx_bytes, r.scr.cap = workspace_bytes - tr->tape_bytes - dx_bytes - side_bytes;
-  backward(r, params, grads, out, grad_out, grad_taps);
+  backward(r, params, grads, out, grad_out, grad_taps, on_group, user);
   if (r.tape.overflow || r.scr.overflow || r.sscr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
   if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
   return 0;

@@ -184,6 +184,33 @@ class _HipEncoderMixin:
         capi.check(capi.load().eec_encoder_profile_read(self._enc, ms, cnt, n), "profile_read")
         return {k: (ms[i], cnt[i]) for i, k in enumerate(capi.KERNEL_CLASSES)}
 
+    # -- data-parallel training (BASELINE.json configs[3]) -----------------------
+    def enable_data_parallel(self, b_local: int, group=None, min_bucket_bytes: int = 4 << 20) -> None:
+        """One process per GPU, every rank holding ``b_local`` utterances of the global batch: from now on the training
+        backward writes the gradients into flat per-exit-group buckets (``parallel.GradBuckets``: ``p.grad`` become views
+        of them) and, as ``eec_train_backward_ex`` reports each finished exit group, starts that bucket's all-reduce
+        (weighted b_local / global batch: the loss is a batch mean, train.py:60-65) on the backend's stream, under the
+        backward of the earlier groups.  Call ``sync_gradients()`` after ``loss.backward()`` and before clipping / the
+        optimizer step.  Collective at set-up: one exchange of the shard sizes.  A no-op without an initialised process
+        group of more than one rank (the buckets are still used, so the single-GPU step runs the same code)."""
+        from . import parallel
+        dev = next(self.parameters()).device
+        named = [(n, p) for n, p in self.named_parameters()]
+        self._dp = {"buckets": parallel.GradBuckets(named, self._cfg.n_exits, min_bucket_bytes=min_bucket_bytes),
+                    "weight": parallel.shard_weight(b_local, dev, group), "group": group, "deferred": [],
+                    "active": parallel._active(group)}
+
+    def sync_gradients(self) -> int:
+        """Join the gradient collectives the last backward started (or run them now if that backward could not use the
+        flat buckets: gradients accumulated into existing ``.grad`` tensors).  Returns the number of collectives joined."""
+        dp = getattr(self, "_dp", None)
+        if dp is None or not dp["active"]:
+            return 0
+        for i in dp["deferred"]:
+            dp["buckets"].allreduce_bucket(i, dp["weight"], dp["group"])
+        dp["deferred"] = []
+        return dp["buckets"].wait()
+
     # -- forward ------------------------------------------------------------
     def _workspace(self, B: int, T: int, device: torch.device) -> Tensor:
         k = (B, T, device.index or 0)
@@ -553,10 +580,13 @@ def greedy_ctc(logp: Tensor, blank: int = 0) -> Tuple[Tensor, Tensor]:
     return tokens, counts
 
 
-def ctc_beam_decode(logp: Tensor, beam_size: int = 10, blank: int = 0, blank_skip_threshold: float = 0.95):
+def ctc_beam_decode(logp: Tensor, beam_size: int = 10, blank: int = 0, blank_skip_threshold: float = 0.95,
+                    skip_drops_frame: bool = False):
     """CTC prefix beam search of [N, T', V] log-probs on the device (eec_ctc_beam_decode): the best hypothesis per
     sequence, as ``BeamInference.ctc_cuda_predict`` uses torchaudio's cuda_ctc_decoder (util/beam_infer.py:102-112).
-    Returns (tokens [N, T'] int32, counts [N] int32, scores [N] fp32)."""
+    ``skip_drops_frame``: a frame above ``blank_skip_threshold`` is dropped instead of being taken as a blank frame (the two
+    readings of the third-party decoder's skip rule, include/eec.h).  Returns (tokens [N, T'] int32, counts [N] int32,
+    scores [N] fp32)."""
     if not logp.is_cuda:
         raise RuntimeError("ctc_beam_decode runs on a HIP device only")
     logp = logp.contiguous().float()
@@ -569,8 +599,8 @@ def ctc_beam_decode(logp: Tensor, beam_size: int = 10, blank: int = 0, blank_ski
     ws = torch.empty((lib.eec_ctc_beam_workspace_bytes(N, Tq),), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         stream = torch.cuda.current_stream(dev).cuda_stream
-        capi.check(lib.eec_ctc_beam_decode(logp.data_ptr(), N, Tq, V, blank, beam_size, blank_skip_threshold, ws.data_ptr(),
-                                           tokens.data_ptr(), counts.data_ptr(), scores.data_ptr(), C.c_void_p(stream)),
+        capi.check(lib.eec_ctc_beam_decode_ex(logp.data_ptr(), N, Tq, V, blank, beam_size, blank_skip_threshold, int(bool(skip_drops_frame)),
+                                              ws.data_ptr(), tokens.data_ptr(), counts.data_ptr(), scores.data_ptr(), C.c_void_p(stream)),
                    "eec_ctc_beam_decode")
     return tokens, counts, scores
 
@@ -592,6 +622,9 @@ class _ExitCtcLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc_out, tg, tl, blank):
         E, B, Tq, V = enc_out.shape
+        if V > 256 or V % 4:
+            raise ValueError(f"exit_ctc_losses with a gradient needs a vocabulary of at most 256 entries, a multiple of 4 (got {V}): "
+                             "the CTC gradient kernel holds a vocabulary row in one wave")
         dev = enc_out.device
         lib = capi.load()
         nll = torch.empty((E * B,), dtype=torch.float32, device=dev)
@@ -786,12 +819,43 @@ class _EncoderTrainFn(torch.autograd.Function):
             for k, v in model.state_dict(keep_vars=True).items():
                 tensors.setdefault(k, v)
             pst, keep = _params_struct(model, tensors)
-            grads = {k: torch.empty_like(v) for k, v in zip(names, params)}
+            # data-parallel mode (enable_data_parallel): gradients are written straight into the flat buckets and each exit
+            # group's bucket is all-reduced as soon as the backward has passed that group.  Only while no parameter holds a
+            # gradient yet (zero_grad(set_to_none=True), the torch default): autograd then installs the views as p.grad;
+            # otherwise it would ADD the view to a p.grad that may alias it, so the step falls back to fresh tensors and
+            # sync_gradients() reduces afterwards.
+            dp = getattr(model, "_dp", None)
+            use_views = dp is not None and all(p.grad is None for p in params)
+            grads = {}
+            for k, v in zip(names, params):
+                view = dp["buckets"].view(k, v) if use_views else None
+                grads[k] = view if view is not None else torch.empty_like(v)
             gst, gkeep = _params_struct(model, grads)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            _trainer_check(lib.eec_train_backward(model._trainer, C.byref(pst), C.byref(gst), out.data_ptr(), g.data_ptr(),
-                                                  g_taps.data_ptr() if g_taps is not None else None, ctx.ws_ptr, ctx.nbytes,
-                                                  C.c_void_p(stream)), "eec_train_backward")
+            cb, err = capi.GROUP_DONE_FN(0), []
+            if dp is not None and dp["active"]:
+                buckets, weight, group = dp["buckets"], dp["weight"], dp["group"]
+                # a bucket may also hold parameters this function does not differentiate (full_conformer's decoders: their
+                # gradients are autograd's own tensors): such buckets, and every bucket when the views are not in use, are
+                # left to sync_gradients()
+                mine = set(names)
+                early = [use_views and all(n in mine for n, _ in b["params"]) for b in buckets.buckets]
+                dp["deferred"] = [i for i, ok in enumerate(early) if not ok]
+
+                def on_group(e, _user):
+                    try:
+                        for i in buckets.buckets_ready_after(e):
+                            if early[i]:
+                                buckets.allreduce_bucket(i, weight, group, trusted=True)
+                    except Exception as ex:  # never unwind through the C frames
+                        err.append(ex)
+                if any(early):
+                    cb = capi.GROUP_DONE_FN(on_group)
+            _trainer_check(lib.eec_train_backward_ex(model._trainer, C.byref(pst), C.byref(gst), out.data_ptr(), g.data_ptr(),
+                                                     g_taps.data_ptr() if g_taps is not None else None, ctx.ws_ptr, ctx.nbytes,
+                                                     C.c_void_p(stream), cb, None), "eec_train_backward")
+            if err:
+                raise err[0]
         ctx.ws = None
         need = ctx.needs_input_grad[5:]
         return (None, None, None, None, None, *[grads[k] if nd else None for k, nd in zip(names, need)])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define EEC_ABI_VERSION 15
+#define EEC_ABI_VERSION 16
 #define EEC_ERR_BAD_ARG 10001
 #define EEC_ERR_UNSUPPORTED 10002
 #define EEC_ERR_WORKSPACE 10003
@@ -238,6 +238,13 @@ int eec_logsoftmax_backward(const float* logp, const float* grad_logp, int M, in
 size_t eec_ctc_beam_workspace_bytes(int n_seq, int Tq);
 int eec_ctc_beam_decode(const float* logp, int n_seq, int Tq, int V, int blank, int beam_size, float blank_skip_threshold,
                         void* workspace, int32_t* tokens, int32_t* counts, float* scores, void* stream);
+/* What torchaudio's CUDA decoder does with a frame above blank_skip_threshold is not visible from the reference (third-party,
+ * absent): eec_ctc_beam_decode takes the frame as a BLANK frame (every prefix's mass moves to "ending in blank": a label
+ * repeated across the frame stays a repeat, "a _ a" -> "aa").  skip_drops_frame != 0 selects the other reading: the frame is
+ * DROPPED, as if the sequence were one frame shorter (the repeat collapses, "a _ a" -> "a"; scores exclude the frame).  Both
+ * are tested against the CPU statement (oracle/ctc_beam_ref.py); the default stays the first until a torchaudio vector pins it. */
+int eec_ctc_beam_decode_ex(const float* logp, int n_seq, int Tq, int V, int blank, int beam_size, float blank_skip_threshold,
+                           int skip_drops_frame, void* workspace, int32_t* tokens, int32_t* counts, float* scores, void* stream);
 
 /* Mel front end: replaces util/data_loader.py:7-18 -- torchaudio Spectrogram(n_fft = 2 * args.n_fft = 1024,
  * hop_length 160, win_length 320; hann window, power 2, centred frames with reflect padding) followed by MelScale(sample_rate,
@@ -282,6 +289,17 @@ int eec_train_forward(eec_trainer* tr, const eec_params* params, const float* me
                       size_t workspace_bytes, void* stream);
 int eec_train_backward(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
                        const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream);
+/* The same backward, reporting its progress: the exit groups are differentiated last to first (train.py:60-68 sums the exit
+ * losses, so the gradient of group e's parameters is final once the backward has passed group e), and `on_group(e, user)` is
+ * called on the host right after the last launch that writes a gradient of exit group e (its layers and its head; e = E-1 ... 0),
+ * then once with e = -1 after the stem.  Everything the callback enqueues on `stream` -- or on a stream that waits for it, as
+ * torch.distributed's collectives do -- therefore runs behind those gradients and beside the backward of the earlier groups:
+ * the hook that lets data-parallel training (BASELINE.json configs[3]) all-reduce bucket e under the backward of group e - 1.
+ * The callback must not call into this library. */
+typedef void (*eec_group_done_fn)(int group, void* user);
+int eec_train_backward_ex(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
+                          const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream, eec_group_done_fn on_group,
+                          void* user);
 /* C = alpha * A . B^T (+ bias) on the training GEMM (test hook): A [M][K], B [N][K], C [M][N] fp32 row-major on the device */
 int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
                    int b_transposed, void* stream);

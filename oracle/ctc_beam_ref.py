@@ -31,9 +31,12 @@ def _lae(a: float, b: float) -> float:
     return m + math.log1p(math.exp(-abs(a - b)))
 
 
-def ctc_prefix_beam_search(logp: np.ndarray, beam: int = 10, blank: int = 0, blank_skip_threshold: float = 0.95, return_beams: bool = False):
+def ctc_prefix_beam_search(logp: np.ndarray, beam: int = 10, blank: int = 0, blank_skip_threshold: float = 0.95, return_beams: bool = False,
+                           skip_drops_frame: bool = False):
     """logp [T', V] natural-log probabilities -> (best prefix, its total log-probability); ``return_beams``: additionally the
-    final beam as [(prefix, total log-probability)] sorted best first."""
+    final beam as [(prefix, total log-probability)] sorted best first.  ``skip_drops_frame``: the other reading of the skip
+    rule -- a frame above the threshold is removed from the sequence (a label repeated across it collapses) instead of being
+    taken as a blank frame."""
     T, V = logp.shape
     log_thr = math.log(blank_skip_threshold) if 0.0 < blank_skip_threshold < 1.0 else 0.0
     beams = [((), 0.0, NEG)]  # (prefix, log p_blank, log p_nonblank)
@@ -41,7 +44,8 @@ def ctc_prefix_beam_search(logp: np.ndarray, beam: int = 10, blank: int = 0, bla
         lp = logp[t].astype(np.float64)
         lpb = float(lp[blank])
         if blank_skip_threshold < 1.0 and lpb > log_thr:
-            beams = [(p, _lae(pb, pnb) + lpb, NEG) for p, pb, pnb in beams]
+            if not skip_drops_frame:
+                beams = [(p, _lae(pb, pnb) + lpb, NEG) for p, pb, pnb in beams]
             continue
         index = {p: i for i, (p, _, _) in enumerate(beams)}
         stay_pb = [_lae(pb, pnb) + lpb for _, pb, pnb in beams]

@@ -192,7 +192,7 @@ def test_aed_training_step_matches_reference_modules():
     import sys
     from conftest import GOLDEN
     sys.path.insert(0, GOLDEN)
-    import make_golden as G
+    import aed_fixture as G
     kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=256, n_head=8, d_feed_forward=256, depthwise_kernel_size=15, dec_voc_size=64)
     common = dict(trg_pad_idx=30, enc_voc_size=64, max_len=400, features_length=80, drop_prob=0.0, n_dec_layers=2)
     gpu = full_conformer(device="cuda", **common, **kw)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(lib):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/eec.h but not exported by libeec.so"
     assert set(capi.EXPORTS) == declared
-    assert lib.eec_abi_version() == 15
+    assert lib.eec_abi_version() == 16
 
 
 def test_trainer_workspace_sizing_runs_without_a_device(lib):
@@ -213,8 +213,76 @@ def test_world2_gloo_bucketed_gradient_allreduce_equals_global_batch_gradient():
     n_coll, err = q.get(timeout=180)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert n_coll >= 3  # the count exchange + more than one bucket
+    assert n_coll >= 2  # more than one bucket (the shard sizes are exchanged once and cached, not per step)
     assert err < 1e-4
+
+
+def _bucket_rank_main(rank, world, port, q):
+    from oracle import conformer_ref as R
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=128, d_model=64, n_head=4)
+        m = R.EarlyConformerRef(**kw).eval()
+        m.load_state_dict(synth.synth_state_dict(m.state_dict(), seed=0, style="trained"))
+        B, T = 6, 99
+        mel, lens = synth.synth_mel(B, 80, T, seed=0), torch.tensor([99, 90, 80, 85, 99, 60])  # every shard holds a full-length utterance
+        tgt, tl = synth.synth_targets(B, 8, 256, seed=0)
+        lo, hi = (0, 4) if rank == 0 else (4, 6)  # unequal shards: the weights b_r / B matter
+        named = list(m.named_parameters())
+        gb = parallel.GradBuckets(named, n_groups=2, min_bucket_bytes=0)
+        order = [b["ready_after"] for b in gb.buckets]
+        w = parallel.shard_weight(hi - lo, torch.device("cpu"))
+        assert parallel.shard_weight(hi - lo, torch.device("cpu")) == w  # cached: no second exchange
+
+        def local_backward():
+            m.zero_grad(set_to_none=True)
+            R.summed_exit_ctc_loss(m(mel[lo:hi], lens[lo:hi]), tgt[lo:hi], tl[lo:hi]).backward()
+
+        # (1) the training backward's protocol: gradients written into the views, buckets reduced as their group finishes
+        local_backward()
+        for n, p in named:
+            v = gb.view(n, p)
+            v.copy_(p.grad)
+            p.grad = v
+        for e in (1, 0, -1):
+            for i in gb.buckets_ready_after(e):
+                gb.allreduce_bucket(i, w, trusted=True)
+        n_wait = gb.wait()
+        got_views = [p.grad.clone() for _, p in named]
+        in_place = all(p.grad.data_ptr() == gb.view(n, p).data_ptr() for n, p in named)
+        # (2) gradients that live outside the buckets (accumulated into older tensors): the gather / scatter path
+        local_backward()
+        n_all = gb.allreduce_all(w)
+        got_plain = [p.grad.clone() for _, p in named]
+        # (3) equal-shard loss combination: mean of the local means, no count exchanged
+        eq = parallel.combine_exit_losses(torch.tensor([1.0 + rank, 3.0 - rank]), 5, equal_shards=True)
+        if rank == 0:
+            m.zero_grad(set_to_none=True)
+            R.summed_exit_ctc_loss(m(mel, lens), tgt, tl).backward()
+            ref = [p.grad for _, p in named]
+            err = lambda got: max(((g - r).abs().max() / (r.abs().max() + 1e-6)).item() for g, r in zip(got, ref))  # noqa: E731
+            q.put((order, n_wait, n_all, in_place, err(got_views), err(got_plain), eq.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_flat_gradient_buckets_reduce_in_place_per_exit_group():
+    """parallel.GradBuckets: one flat bucket per exit group in the order the backward finishes them (last group first, stem
+    last); reducing the buckets as the groups finish, in place, equals the gradient of the global-batch mean loss with unequal
+    shards; gradients outside the buckets take the gather path to the same result; the shard weight is exchanged once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    order, n_wait, n_all, in_place, err_views, err_plain, eq = q.get(timeout=180)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert order == [1, 0, -1] and n_wait == 3 and n_all == 3 and in_place
+    assert err_views < 1e-4 and err_plain < 1e-4
+    assert eq == pytest.approx([1.5, 2.5])
 
 
 def _run_bench(extra_env, *argv):
@@ -244,6 +312,28 @@ def test_bench_launcher_propagates_a_failed_rank():
     res = _run_bench({"EEC_BENCH_FAIL_RANK": "1"}, "--gpus", "2", "--steps", "1")
     assert res.returncode == 7
     assert "rank 1 exited with status 7" in res.stderr
+
+
+def test_bench_rank_failing_inside_a_step_fails_the_job():
+    """A rank that raises inside a training step skips collectives its peers wait in.  It must leave with a non-zero status
+    (never a record with rc 0): the launcher then terminates the stuck peers and propagates the status; when the failing rank
+    is rank 0 the record is still emitted once, with the error in place of the training-step lines."""
+    import json
+    res = _run_bench({"EEC_BENCH_FAIL_STEP_RANK": "1", "EEC_BENCH_TRAIN_TIMEOUT": "60"}, "--gpus", "2", "--steps", "1")
+    assert res.returncode == 4, (res.returncode, res.stderr)
+    assert "rank 1 exited with status 4" in res.stderr
+    assert len([ln for ln in res.stdout.splitlines() if ln.startswith("{")]) <= 1
+    res = _run_bench({"EEC_BENCH_FAIL_STEP_RANK": "0", "EEC_BENCH_TRAIN_TIMEOUT": "60"}, "--gpus", "2", "--steps", "1")
+    assert res.returncode == 4, (res.returncode, res.stderr)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and "injected failure" in json.loads(lines[0])["train_step"]["error"]
+
+
+def test_bench_hung_section_ends_non_zero():
+    """The watchdog of the last section ends a hung run with a NON-ZERO status after emitting the record."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    guard = src[src.index("class RecordGuard"):src.index("def plumbing_check")]
+    assert "os._exit(0)" not in src and "os._exit(code)" in guard and ", 3)" in guard
 
 
 def test_bench_parent_makes_no_gpu_call_before_spawning():

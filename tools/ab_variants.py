@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of library builds on the GPU box: interleaved rounds, one subprocess per (round, variant).
 
-    python tools/ab_variants.py [--rounds 3] base=early_exit_transformer_amd/csrc/libeec.so v1=.../libeec_v1.so ...
+    python tools/ab_variants.py [--rounds 3] base=early_exit_transformer_amd/csrc/libeec.so v1=.../libeec_v1.so[,ENV=VAL] ...
 
 Each run times the default-config forward (B = 64, T = 1027, f16f8; median of 30 after 5 warm-ups) and the mean
 chain-kernel launch (HIP events).  Prints per-variant median / min over the rounds."""
@@ -46,7 +46,9 @@ def main():
     res = {n: [] for n, _ in variants}
     for r in range(rounds):
         for n, path in variants:
+            path, *extra = path.split(",")  # name=path[,KEY=VAL ...]: extra environment for this variant
             env = dict(os.environ, EEC_LIB_PATH=os.path.abspath(path))
+            env.update(dict(kv.split("=", 1) for kv in extra))
             out = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True)
             line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
             if not line:

@@ -29,3 +29,5 @@ for nm, ph in names.items():
         for wv in (0, 1):
             t = a[blk, wv, :len(ph) + 1]
             print(f"  block {blk} wave {'0L'[wv]}: total {t[-1]-t[0]:6d} | " + " ".join(f"{int(v):5d}" for v in np.diff(t)))
+            if nm == "glu" and a[blk, wv, 11] > 0:  # fused attention prologue: stamps 11..15 relative to the kernel entry
+                print("      attention: Q + first fetch issued / key blocks 0, 1, 2, 3 done at " + " ".join(f"{int(v - a[blk, wv, 0]):6d}" for v in a[blk, wv, 11:16]))
