@@ -91,6 +91,7 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
            "eec_train_forward", "eec_train_backward", "eec_train_backward_ex", "eec_train_gemm",
            "eec_decoder_last_error", "eec_decoder_workspace_bytes", "eec_decoder_forward",
+           "eec_decoder_train_last_error", "eec_decoder_train_workspace_bytes", "eec_decoder_train_forward", "eec_decoder_train_backward",
            "eec_decoder_step_last_error", "eec_decoder_step_max_beams", "eec_decoder_cache_bytes", "eec_decoder_begin", "eec_decoder_step", "eec_decoder_step_multi", "eec_upload_i64_max", "eec_upload_i64", "eec_beam_select"]
 KERNEL_CLASSES = ["stem", "ffn", "qkv", "attn", "proj_glu", "proj", "dw_pw2", "head", "chain"]
 
@@ -170,6 +171,15 @@ def load() -> C.CDLL:
     lib.eec_decoder_workspace_bytes.restype = C.c_size_t
     lib.eec_decoder_forward.argtypes = [C.POINTER(EecDecoderParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                         C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_decoder_train_last_error.restype = C.c_char_p
+    lib.eec_decoder_train_workspace_bytes.argtypes = [C.c_int] * 8
+    lib.eec_decoder_train_workspace_bytes.restype = C.c_size_t
+    lib.eec_decoder_train_forward.argtypes = [C.POINTER(EecDecoderParams), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p,
+                                              C.c_size_t, C.c_void_p]
+    lib.eec_decoder_train_backward.argtypes = [C.POINTER(EecDecoderParams), C.POINTER(EecDecoderParams), C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_decoder_step_last_error.restype = C.c_char_p
     lib.eec_decoder_cache_bytes.argtypes = [C.c_int] * 7
     lib.eec_decoder_cache_bytes.restype = C.c_size_t

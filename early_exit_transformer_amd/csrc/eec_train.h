@@ -33,7 +33,7 @@ struct GemmArgs {
   const float* bias;
   int accumulate;
   // epilogue (single [M][N] problems only): 0 none; 1: C2 = drop(silu(C)); 2: C = C * dropmask * silu'(aux); 3: C = max(C, 0);
-  // 4: C = aux + res_scale * drop(C)  (the residual connection around a sub-module)
+  // 4: C = aux + res_scale * drop(C)  (the residual connection around a sub-module); 5: C2 = drop(max(C, 0)); 6: C = C * dropmask * (aux > 0)
   int epi;
   float* C2;
   const float* aux;
@@ -107,6 +107,15 @@ hipError_t launch_attn_bwd_fused(const float* qkv, const int32_t* key_len, const
 // AED decoder helpers (decoder.hip).  P[z][tq][:] = softmax(scale * S[z][tq][:] + mask) in place over [B*H][Tq][Tk] scores:
 // key tk is masked for query tq of batch b = z / H when (causal && tk > tq) || (key_pad && key_pad[b * Tk + tk])
 hipError_t launch_softmax_masked(float* S, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad, hipStream_t st);
+// the same with the dropped copy Pd = drop(P) written in the same pass (Pd may be null), and the backward of any such softmax over
+// `rows` rows of Tk probabilities: dS = scale * P * (dPd * dropmask - sum_k(dPd * dropmask * P)) in place over dP
+hipError_t launch_softmax_masked_drop(float* S, float* Pd, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad,
+                                      Drop d, hipStream_t st);
+hipError_t launch_softmax_bwd_rows(const float* P, float* dP, long rows, int Tk, float scale, Drop d, hipStream_t st);
+// train mode: x = drop(emb[tok] + pe) (positional_encoder_2's dropout); demb[v] = sum of the (masked) dx rows of the tokens equal to v
+hipError_t launch_embed_pe_drop(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
+                                int pad_idx, Drop d, hipStream_t st);
+hipError_t launch_embed_bwd(const long long* tok, const float* dx, float* demb, long n_tok, int D, int V, Drop d, hipStream_t st);
 // x[i][:] = emb[tok[i]][:] + pe[i % S][:];  pad[i] = (tok[i] == pad_idx)
 hipError_t launch_embed_pe(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
                            int pad_idx, hipStream_t st);

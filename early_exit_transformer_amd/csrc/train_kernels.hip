@@ -208,7 +208,8 @@ struct FastTag {
 };
 
 // epilogue variants: C = v;  EPI_SILU: also C2 = drop(silu(v));  EPI_DSILU: C = v * dropmask * silu'(aux)
-enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3, EPI_RESID = 4 };
+// EPI_RELU_DROP: C = v, C2 = drop(relu(v));  EPI_DRELU: C = v * dropmask * (aux > 0)   (the ReLU feed-forward of the AED decoder)
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3, EPI_RESID = 4, EPI_RELU_DROP = 5, EPI_DRELU = 6 };
 
 // STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
 // contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // ahead: the loads of slab s + 1 are in flight while slab s goes through LDS and out
   constexpr int NPS = 32 * (BN / 4) / 256;
   f32x4 pre[BM / 32][NPS];
-  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU || g.epi == EPI_RESID);
+  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU || g.epi == EPI_RESID || g.epi == EPI_DRELU);
   const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
   auto request = [&](auto sl_tag) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_tag)::value;
@@ -409,6 +410,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
           }
+          if (g.epi == EPI_DRELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= pre[sl][ps][j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
+          }
           if (g.epi == EPI_RESID) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pre[sl][ps][j] + g.res_scale * v[j] * ds.mul((uint64_t)(ci + j));
@@ -417,6 +422,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           if (g.epi == EPI_SILU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * ds.mul((uint64_t)(ci + j));
+            *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+          }
+          if (g.epi == EPI_RELU_DROP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v2[j] = fmaxf(v[j], 0.0f) * ds.mul((uint64_t)(ci + j));
             *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
           }
         } else {
@@ -430,9 +440,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
                 t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
               }
               if (g.epi == EPI_RELU) t = fmaxf(t, 0.0f);
+              if (g.epi == EPI_DRELU) t *= aux[ci + j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
               if (g.epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
               C[ci + j] = t;
               if (g.epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
+              if (g.epi == EPI_RELU_DROP) C2[ci + j] = fmaxf(t, 0.0f) * ds.mul((uint64_t)(ci + j));
             }
           }
         }
@@ -1057,6 +1069,12 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
     for (int k = lane; k < T; k += 64) g[k] = scale * p[k] * (g[k] * ds.mul((uint64_t)(row * T + k)) - dot);
   }
 }
+// rectangular form: `rows` rows of Tk probabilities (the AED decoder's self- / cross-attention); dropout stream position = flat index
+hipError_t launch_softmax_bwd_rows(const float* P, float* dP, long rows, int Tk, float scale, Drop d, hipStream_t st) {
+  if (Tk <= 64 * kSmMax) hipLaunchKernelGGL(softmax_bwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, Tk, scale, d);
+  else hipLaunchKernelGGL(softmax_bwd_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, Tk, scale, d);
+  return hipGetLastError();
+}
 hipError_t launch_softmax_bwd(const float* P, float* dP, int B, int H, int T, float scale, Drop d, hipStream_t st) {
   const long rows = (long)B * H * T;
   if (T <= 64 * kSmMax) hipLaunchKernelGGL(softmax_bwd_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, P, dP, rows, T, scale, d);
@@ -1085,10 +1103,11 @@ hipError_t launch_logsoftmax_fwd(const float* logits, float* logp, int M, int V,
 // AED decoder helpers
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void softmax_masked_kernel(float* __restrict__ S, long rows, int H, int Tq, int Tk, float scale, int causal,
-                                                             const unsigned char* __restrict__ key_pad) {
+                                                             const unsigned char* __restrict__ key_pad, float* __restrict__ Pd, Drop d) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
+  const DropState dst(d);
   const int tq = (int)(row % Tq);
   const long b = row / ((long)H * Tq);
   const unsigned char* pad = key_pad ? key_pad + b * Tk : nullptr;
@@ -1100,25 +1119,60 @@ __global__ __launch_bounds__(256) void softmax_masked_kernel(float* __restrict__
   float sum = 0.0f;
   for (int k = lane; k < Tk; k += 64) sum += live(k) ? __expf(s[k] * scale - mx) : 0.0f;
   const float inv = 1.0f / wave_sum(sum);  // no live key: nan in every column, as torch
-  for (int k = lane; k < Tk; k += 64) s[k] = live(k) ? __expf(s[k] * scale - mx) * inv : (mx == -INFINITY ? NAN : 0.0f);
+  for (int k = lane; k < Tk; k += 64) {
+    const float p = live(k) ? __expf(s[k] * scale - mx) * inv : (mx == -INFINITY ? NAN : 0.0f);
+    s[k] = p;
+    if (Pd) Pd[row * Tk + k] = p * dst.mul((uint64_t)(row * Tk + k));
+  }
 }
 hipError_t launch_softmax_masked(float* S, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad, hipStream_t st) {
+  return launch_softmax_masked_drop(S, nullptr, B, H, Tq, Tk, scale, causal, key_pad, Drop{0.0f, 0, 0}, st);
+}
+hipError_t launch_softmax_masked_drop(float* S, float* Pd, int B, int H, int Tq, int Tk, float scale, int causal, const unsigned char* key_pad,
+                                      Drop d, hipStream_t st) {
   const long rows = (long)B * H * Tq;
-  hipLaunchKernelGGL(softmax_masked_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, H, Tq, Tk, scale, causal, key_pad);
+  hipLaunchKernelGGL(softmax_masked_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, S, rows, H, Tq, Tk, scale, causal, key_pad, Pd, d);
   return hipGetLastError();
 }
 __global__ __launch_bounds__(256) void embed_pe_kernel(const long long* __restrict__ tok, const float* __restrict__ emb, const float* __restrict__ pe,
-                                                       float* __restrict__ x, unsigned char* __restrict__ pad, long n_tok, int S, int D, int V, int pad_idx) {
+                                                       float* __restrict__ x, unsigned char* __restrict__ pad, long n_tok, int S, int D, int V, int pad_idx,
+                                                       Drop d) {
   const long i = blockIdx.x;
   if (i >= n_tok) return;
+  const DropState ds(d);
   const long long t = tok[i];
   const long long tc = t < 0 ? 0 : (t >= V ? V - 1 : t);  // nn.Embedding would raise; stay in bounds
   if (threadIdx.x == 0 && pad) pad[i] = t == pad_idx;
-  for (int c = threadIdx.x; c < D; c += 256) x[i * D + c] = emb[tc * D + c] + pe[(i % S) * D + c];
+  for (int c = threadIdx.x; c < D; c += 256) x[i * D + c] = (emb[tc * D + c] + pe[(i % S) * D + c]) * ds.mul((uint64_t)(i * D + c));
 }
 hipError_t launch_embed_pe(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
                            int pad_idx, hipStream_t st) {
-  hipLaunchKernelGGL(embed_pe_kernel, dim3((unsigned)n_tok), dim3(256), 0, st, tok, emb, pe, x, pad, n_tok, S, D, V, pad_idx);
+  return launch_embed_pe_drop(tok, emb, pe, x, pad, n_tok, S, D, V, pad_idx, Drop{0.0f, 0, 0}, st);
+}
+hipError_t launch_embed_pe_drop(const long long* tok, const float* emb, const float* pe, float* x, unsigned char* pad, long n_tok, int S, int D, int V,
+                                int pad_idx, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(embed_pe_kernel, dim3((unsigned)n_tok), dim3(256), 0, st, tok, emb, pe, x, pad, n_tok, S, D, V, pad_idx, d);
+  return hipGetLastError();
+}
+// demb[v][:] = sum over the tokens i with tok[i] == v (clamped like the forward) of dx[i][:] * dropmask(i, :), in token order:
+// one workgroup per vocabulary entry walks the token list, so the sum has a fixed order (no atomics)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dx, float* __restrict__ demb,
+                                                        long n_tok, int D, int V, Drop d) {
+  const int v = blockIdx.x;
+  const DropState ds(d);
+  for (int c0 = 0; c0 < D; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    float acc = 0.0f;
+    for (long i = 0; i < n_tok; ++i) {
+      const long long t = tok[i];
+      const long long tc = t < 0 ? 0 : (t >= V ? V - 1 : t);
+      if (tc == v && c < D) acc += dx[i * D + c] * ds.mul((uint64_t)(i * D + c));
+    }
+    if (c < D) demb[(long)v * D + c] = acc;
+  }
+}
+hipError_t launch_embed_bwd(const long long* tok, const float* dx, float* demb, long n_tok, int D, int V, Drop d, hipStream_t st) {
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((unsigned)V), dim3(256), 0, st, tok, dx, demb, n_tok, D, V, d);
   return hipGetLastError();
 }
 

@@ -297,11 +297,14 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
 
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
         if self.training and type(self) is Early_conformer:
-            # train-mode semantics (batch-statistics BatchNorm, dropout) whenever the module is in train mode -- with or
-            # without autograd, as the reference; the one exception is the frozen-encoder case below
-            if not torch.is_grad_enabled() or any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("linears.")):
-                return self._forward_train(src, lengths)
-            return self._forward_heads_trainable(src, lengths)
+            # train-mode semantics (batch-statistics BatchNorm, dropout, running-statistics update) whenever the module is in
+            # train mode -- with or without autograd, whatever requires_grad says, as the reference.  The one exception is an
+            # explicit opt-in: ``model.frozen_encoder_eval = True`` runs a FROZEN encoder (only linears.* trainable) on the fused
+            # inference path in eval semantics and trains the heads on its taps (cheaper; not what the reference computes).
+            frozen = not any(p.requires_grad for n, p in self.named_parameters() if not n.startswith("linears."))
+            if torch.is_grad_enabled() and frozen and getattr(self, "frozen_encoder_eval", False):
+                return self._forward_heads_trainable(src, lengths)
+            return self._forward_train(src, lengths)
         if self.training and torch.is_grad_enabled():
             return self._forward_heads_trainable(src, lengths)
         return self._run_encoder(src, lengths)[0]
@@ -990,10 +993,80 @@ class DecoderSessionGroup:
         return out
 
 
+class _DecoderTrainFn(torch.autograd.Function):
+    """Exit ``idx``'s attention decoder in train mode and its backward on the HIP training kernels (eec_decoder_train_forward /
+    _backward): ``linears_2[idx](decoders[idx](positional_encoder_2(emb(trg)), enc, causal + padding masks))`` -> raw logits
+    [B, S, V], differentiable with respect to every decoder parameter, the embedding table and ``enc`` (the encoder tap)."""
+
+    @staticmethod
+    def forward(ctx, model, idx, trg, enc, seed, names, *params):
+        lib = capi.load()
+        dev = trg.device
+        cfg = model._cfg
+        Bm, S = trg.shape
+        Tq = enc.size(1)
+        if enc.size(0) != Bm or enc.size(2) != cfg.d_model:
+            raise ValueError(f"enc must be [{Bm}, T', {cfg.d_model}], got {tuple(enc.shape)}")
+        tensors = dict(zip(names, params))
+        for k, t in tensors.items():
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"parameter {k} must be a contiguous fp32 tensor on {dev}")
+        d_ff = model.decoders[idx].layers[0].linear1.out_features
+        V = model.linears_2[idx].out_features
+        n_layers = len(model.decoders[idx].layers)
+        with torch.cuda.device(dev):
+            ps, keep = model._decoder_struct(idx, tensors, with_pe=True)
+            nbytes = lib.eec_decoder_train_workspace_bytes(cfg.d_model, cfg.n_heads, d_ff, V, n_layers, Bm, S, Tq)
+            if nbytes == 0:
+                raise ValueError("unsupported geometry for the decoder's training step")
+            ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+            ws_ptr = (ws.data_ptr() + 255) // 256 * 256
+            out = torch.empty((Bm, S, V), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            geo = (cfg.d_model, cfg.n_heads, d_ff, V)
+            rc = lib.eec_decoder_train_forward(C.byref(ps), *geo, int(model.trg_pad_idx), trg.data_ptr(), enc.data_ptr(), Bm, S, Tq,
+                                               int(model.decoder_passes), float(model.dropout), int(seed), int(idx), out.data_ptr(), ws_ptr, nbytes,
+                                               C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_train_forward failed (code {rc}): {lib.eec_decoder_train_last_error().decode(errors='replace')}")
+        ctx.model, ctx.idx, ctx.names, ctx.seed, ctx.geo = model, idx, names, int(seed), geo
+        ctx.ws, ctx.ws_ptr, ctx.nbytes, ctx.drop, ctx.passes = ws, ws_ptr, nbytes, float(model.dropout), int(model.decoder_passes)
+        ctx.save_for_backward(trg, enc, *params)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.ws is None:
+            raise RuntimeError("the decoder's recorded forward was already consumed by a backward")
+        model, idx, names = ctx.model, ctx.idx, ctx.names
+        trg, enc, params = ctx.saved_tensors[0], ctx.saved_tensors[1], ctx.saved_tensors[2:]
+        dev = trg.device
+        lib = capi.load()
+        Bm, S = trg.shape
+        Tq = enc.size(1)
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            tensors = dict(zip(names, params))
+            ps, keep = model._decoder_struct(idx, tensors, with_pe=True)
+            grads = {k: torch.empty_like(v) for k, v in tensors.items()}
+            gs, gkeep = model._decoder_struct(idx, grads, with_pe=False)
+            g_enc = torch.empty_like(enc)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.eec_decoder_train_backward(C.byref(ps), C.byref(gs), *ctx.geo, trg.data_ptr(), enc.data_ptr(), Bm, S, Tq, ctx.passes, ctx.drop,
+                                                ctx.seed, int(idx), g.data_ptr(), g_enc.data_ptr(), ctx.ws_ptr, ctx.nbytes, C.c_void_p(stream))
+            if rc != 0:
+                raise RuntimeError(f"eec_decoder_train_backward failed (code {rc}): {lib.eec_decoder_train_last_error().decode(errors='replace')}")
+        ctx.ws = None
+        need = ctx.needs_input_grad[6:]
+        return (None, None, None, g_enc if ctx.needs_input_grad[3] else None, None, None,
+                *[grads[k] if nd else None for k, nd in zip(names, need)])
+
+
 class full_conformer(_HipEncoderMixin, nn.Module):
-    """AED model: HIP encoder + the attention decoder.  Inference (``_decoder_``, ``forward`` without autograd) runs the
-    decoder on the hand-written path too (csrc/decoder.hip); with autograd the decoder is the reference's
-    ``nn.TransformerDecoder`` on PyTorch-ROCm (its parameters are the same tensors either way)."""
+    """AED model: HIP encoder + the attention decoder, both on the hand-written path: inference through csrc/decoder.hip /
+    decoder_step.hip, training (forward in train mode + backward, train.py:36-52) through csrc/decoder_train.hip
+    behind an autograd function.  The ``nn.TransformerDecoder`` modules only hold the parameters (state_dict contract)."""
 
     _head_attr = "linears_1"
     _pe_attr = "positional_encoder_1"
@@ -1033,16 +1106,41 @@ class full_conformer(_HipEncoderMixin, nn.Module):
 
     decoder_passes = 3  # the HIP decoder's GEMM operands: 3 = bf16 hi/lo split (~1e-5 of fp32), 1 = plain bf16
 
-    def _decode_one(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool = False) -> Tensor:
-        if trg.is_cuda and not (self.training and torch.is_grad_enabled()):
-            return self._hip_decoder(trg, enc, idx, log_softmax)  # inference: the hand-written path (csrc/decoder.hip)
-        # training with autograd: the reference's own modules on PyTorch-ROCm (the decoder's backward is not built)
-        sz = trg.size(1)
-        tgt_mask = torch.triu(torch.full((sz, sz), float("-inf"), device=trg.device), diagonal=1)
-        pad_mask = trg == self.trg_pad_idx
-        t = self.positional_encoder_2(self.emb(trg))
-        out = self.linears_2[idx](self.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=pad_mask))
+    def _decode_one(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool = False, seed: Optional[int] = None) -> Tensor:
+        if not trg.is_cuda:
+            raise RuntimeError("the MI355X decoder runs on a HIP device only (there is no CPU fallback)")
+        if not (self.training and torch.is_grad_enabled()):
+            return self._hip_decoder(trg, enc, idx, log_softmax)  # inference: csrc/decoder.hip
+        # training with autograd (train.py:36-52): forward and backward on the HIP training kernels (csrc/decoder_train.hip)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        named = self._decoder_named_params(idx)
+        out = _DecoderTrainFn.apply(self, idx, trg.to(torch.int64).contiguous(), enc.contiguous().float(), seed,
+                                    tuple(n for n, _ in named), *[p for _, p in named])
         return torch.log_softmax(out, dim=2) if log_softmax else out
+
+    def _decoder_named_params(self, idx: int):
+        """(name, parameter) of everything exit ``idx``'s decoder reads, under the model's state_dict names (the decoders'
+        final norm is the ONE shared ``layer_norm``, early_exit.py:666,701-717)."""
+        named = [("emb.weight", self.emb.weight), ("layer_norm.weight", self.layer_norm.weight), ("layer_norm.bias", self.layer_norm.bias),
+                 (f"linears_2.{idx}.weight", self.linears_2[idx].weight), (f"linears_2.{idx}.bias", self.linears_2[idx].bias)]
+        for l, layer in enumerate(self.decoders[idx].layers):
+            sd = dict(layer.named_parameters())
+            named += [(f"decoders.{idx}.layers.{l}.{suffix}", sd[suffix]) for suffix in capi.DECODER_LAYER_KEYS.values()]
+        return named
+
+    def _decoder_struct(self, idx: int, tensors: Dict[str, Tensor], with_pe: bool):
+        """eec_decoder_params over ``tensors`` (name -> tensor: the parameters themselves, or gradient buffers of their shapes)."""
+        n_layers = len(self.decoders[idx].layers)
+        layers = (capi.EecDecoderLayerParams * n_layers)()
+        for l in range(n_layers):
+            for field, suffix in capi.DECODER_LAYER_KEYS.items():
+                setattr(layers[l], field, tensors[f"decoders.{idx}.layers.{l}.{suffix}"].data_ptr())
+        pe = self.positional_encoder_2.pe
+        ps = capi.EecDecoderParams(tensors["emb.weight"].data_ptr(), pe.data_ptr() if with_pe else None, layers, n_layers, pe.size(0),
+                                   tensors["layer_norm.weight"].data_ptr(), tensors["layer_norm.bias"].data_ptr(),
+                                   tensors[f"linears_2.{idx}.weight"].data_ptr(), tensors[f"linears_2.{idx}.bias"].data_ptr())
+        return ps, layers
 
     def _decoder_params(self, idx: int, dev):
         """The C-ABI view (eec_decoder_params) of exit ``idx``'s decoder: pointers into the module's own parameters, rebuilt
@@ -1136,7 +1234,11 @@ class full_conformer(_HipEncoderMixin, nn.Module):
             # train.py:36-52 (aed): encoder forward / backward on the HIP training kernels, the decoders (autograd through the
             # reference's nn.TransformerDecoder on PyTorch-ROCm) consume the differentiable taps
             enc_out, taps = Early_conformer._forward_train(self, src, lengths, want_taps=True)
-            dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
+            if not torch.is_grad_enabled():
+                dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
+                return dec_out, enc_out
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # one seed per forward: the exits share the embedding's dropout mask
+            dec_out = torch.stack([self._decode_one(trg, taps[e], e, seed=seed) for e in range(self._cfg.n_exits)])
             return dec_out, enc_out
         enc_out, taps, _ = self._run_encoder(src, lengths, want_taps=True)
         dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])

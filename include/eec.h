@@ -336,6 +336,28 @@ int eec_decoder_forward(const eec_decoder_params* p, int d_model, int n_heads, i
                         void* workspace, size_t workspace_bytes, void* stream);
 
 
+/* ---- Training step of the AED decoder (csrc/decoder_train.hip): what autograd does through the decoder half of
+ * full_conformer.forward in train mode (early_exit.py:764-800; train.py:36-52, --decoder_mode aed) -----------------------------
+ * eec_decoder_train_forward: out [Bm][S][V] = RAW logits (the reference comments the log_softmax out, early_exit.py:790) of exit
+ * `exit_index`'s decoder on targets trg [Bm][S] (int64; pad_idx positions masked as keys) over the memory enc [Bm][Tq][D], with
+ * dropout of probability drop_prob at the reference's sites (after the positional encoding -- site shared by the exits of a
+ * forward, the reference embeds the targets once --, on both attention-probability tensors, after the three sub-modules, inside
+ * the feed-forward), from the counter-based generator keyed by (seed, exit_index).  It records what the backward needs in
+ * `workspace` (eec_decoder_train_workspace_bytes; 256-byte aligned; keep it untouched until the backward).
+ * eec_decoder_train_backward (same geometry, trg, enc, seed, drop_prob, exit_index): grad_out = dLoss / d out; `grads` mirrors
+ * `p` with pointers that are WRITTEN with the gradient of the parameter in the same position (emb [V][D]; pe ignored; layers a
+ * host array); grad_enc [Bm][Tq][D] is written with the gradient of the memory (what flows on into the encoder's backward as
+ * eec_train_backward's grad_taps).  The shared final LayerNorm and the embedding receive one such gradient per exit: the caller
+ * sums them (autograd does).  Parity with the reference's modules is at drop_prob 0 (its dropout streams cannot match). */
+const char* eec_decoder_train_last_error(void);
+size_t eec_decoder_train_workspace_bytes(int d_model, int n_heads, int d_ff, int vocab, int n_layers, int Bm, int S, int Tq);
+int eec_decoder_train_forward(const eec_decoder_params* p, int d_model, int n_heads, int d_ff, int vocab, int pad_idx, const int64_t* trg,
+                              const float* enc, int Bm, int S, int Tq, int passes, float drop_prob, uint64_t seed, int exit_index, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int eec_decoder_train_backward(const eec_decoder_params* p, const eec_decoder_params* grads, int d_model, int n_heads, int d_ff, int vocab,
+                               const int64_t* trg, const float* enc, int Bm, int S, int Tq, int passes, float drop_prob, uint64_t seed,
+                               int exit_index, const float* grad_out, float* grad_enc, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- Step-wise AED decoding with a key / value cache (csrc/decoder_step.hip) ----------------------------------------------------
  * What util/beam_infer.py:233-240 needs from `_decoder_` is the LAST position's log-probs of every live beam; the reference gets
  * them by re-running the decoder over the whole prefix at every step.  A session here is a caller-owned device buffer `cache`

@@ -42,3 +42,21 @@ def load_golden(name):
     z = np.load(os.path.join(GOLDEN, f"{name}.npz"))
     kw = base_kwargs(**eval(str(z["kwargs"])))  # the dict literal written by make_golden.py
     return z, kw
+
+
+def ref_decoder_logits(model, trg, enc, idx):
+    """TEST-SIDE reference of the AED decoder: the reference's arithmetic (early_exit.py:739-762, 776-790) through the torch
+    modules that hold the product class's parameters -- embedding, positional encoding, nn.TransformerDecoder (norm_first, causal
+    + target-padding masks, shared final LayerNorm), linears_2[idx] -- on whatever device they are (the CPU in the tests).  Raw
+    logits.  The product itself never runs these modules (it has no CPU path)."""
+    sz = trg.size(1)
+    tgt_mask = torch.triu(torch.full((sz, sz), float("-inf"), device=trg.device), diagonal=1)
+    t = model.positional_encoder_2(model.emb(trg))
+    return model.linears_2[idx](model.decoders[idx](t, enc, tgt_mask=tgt_mask, tgt_key_padding_mask=trg == model.trg_pad_idx))
+
+
+def ref_decoder_logprobs(model, trg, enc, layer_n):
+    """``_decoder_`` of the reference (log-probs; layer_n counts from 1, out-of-range values select the last exit)."""
+    n = model.n_enc_exits
+    idx = (int(layer_n) if 1 <= int(layer_n) <= n else n) - 1
+    return torch.log_softmax(ref_decoder_logits(model, trg, enc, idx), dim=2)

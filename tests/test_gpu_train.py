@@ -12,7 +12,7 @@ import ctypes as C
 import pytest
 import torch
 
-from conftest import base_kwargs
+from conftest import base_kwargs, ref_decoder_logits
 from early_exit_transformer_amd import capi, synth
 from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses, full_conformer
 from oracle import conformer_ref as R
@@ -113,6 +113,84 @@ def test_training_step_matches_oracle_autograd(cfg, B, T, lens):
     compare_grads(grads_of(gpu), grads_of(ref), 0.15, "bf16")
 
 
+@pytest.mark.parametrize("cfg,B,T,lens,tol", [
+    # BASELINE.json configs[3]'s model in full depth: the default 12-layer d_model 256 network (6 exits x 2), T' = 256
+    (dict(), 4, 1027, [1027, 903, 771, 642], 3e-3),
+    # configs[2]'s geometry in full depth: 18 layers (6 exits x 3) at d_model 512, head dim 64; d_ff reduced for the CPU oracle's time
+    (dict(d_model=512, n_enc_layers=3, d_feed_forward=512), 2, 515, [515, 400], 3e-3),
+], ids=["default_12_layers", "18_layers_d512"])
+def test_deep_training_step_matches_oracle_autograd(cfg, B, T, lens, tol):
+    """Depth is what the shallow cases above do not cover: the bf16x3 rounding of every GEMM accumulates through 12 / 18 layers
+    of forward and backward.  Same comparison (train.py:53-68: train-mode forward, summed exit CTC losses, backward; dropout 0
+    so that the oracle's autograd is comparable), every one of the 413 / 605 parameter gradients."""
+    kw = base_kwargs(**cfg)
+    ref, gpu = make_train_pair(kw, seed=41)
+    mel, lens = synth.synth_mel(B, 80, T, seed=41), torch.tensor(lens)
+    tgt, tl = synth.synth_targets(B, 20, kw["dec_voc_size"], seed=41)
+    want_out = ref(mel, lens)
+    want_loss = R.summed_exit_ctc_loss(want_out, tgt, tl)
+    want_loss.backward()
+    out = gpu(mel.cuda(), lens)
+    err = (out.detach().cpu() - want_out.detach()).abs().max().item()
+    print(f"\n[deep train fwd] {kw['n_enc_exits'] * kw['n_enc_layers']} layers, d_model {kw['d_model']}: max |dlogp| vs the oracle in train mode: {err:.2e}")
+    assert err < 5e-4
+    loss = exit_ctc_losses(out, tgt, tl).sum()
+    assert abs(loss.item() - want_loss.item()) < 3e-4 * max(1.0, abs(want_loss.item()))
+    loss.backward()
+    compare_grads(grads_of(gpu), grads_of(ref), tol, f"bf16x3, {kw['n_enc_exits'] * kw['n_enc_layers']} layers")
+
+
+def test_frozen_encoder_keeps_train_mode_semantics():
+    """model.train() with only linears.* trainable: the reference still normalises with BATCH statistics (and updates the
+    running ones); so does the default here (the eval-semantics shortcut is an explicit opt-in, model.frozen_encoder_eval)."""
+    kw = base_kwargs(**SMALL)
+    ref, gpu = make_train_pair(kw, seed=43)
+    for m in (ref, gpu):
+        for n, p in m.named_parameters():
+            p.requires_grad_(n.startswith("linears."))
+    mel, lens = synth.synth_mel(3, 80, 131, seed=43), torch.tensor([131, 90, 57])
+    tgt, tl = synth.synth_targets(3, 9, kw["dec_voc_size"], seed=43)
+    want_out = ref(mel, lens)
+    R.summed_exit_ctc_loss(want_out, tgt, tl).backward()
+    out = gpu(mel.cuda(), lens)
+    assert (out.detach().cpu() - want_out.detach()).abs().max().item() < 2e-4
+    exit_ctc_losses(out, tgt, tl).sum().backward()
+    for e in range(kw["n_enc_exits"]):
+        gw = ref.linears[e].weight.grad
+        assert (gpu.linears[e].weight.grad.cpu() - gw).abs().max().item() < 2e-3 * gw.abs().max().item()
+    assert all(p.grad is None for n, p in gpu.named_parameters() if not n.startswith("linears."))
+    for (n, b_ref), (_, b_gpu) in zip(ref.named_buffers(), gpu.named_buffers()):
+        if "running_" in n:
+            assert torch.allclose(b_gpu.cpu().float(), b_ref.float(), rtol=1e-4, atol=1e-6), n
+
+
+def test_data_parallel_buckets_hold_the_same_gradients():
+    """enable_data_parallel (one rank: no collective): the backward writes every gradient into the flat per-exit-group buckets,
+    p.grad ARE views of them, values equal the plain backward's bit for bit; a second backward onto existing gradients
+    (no zero_grad) falls back to fresh tensors and accumulates like autograd always does."""
+    kw = base_kwargs(**SMALL)
+    _, gpu = make_train_pair(kw, seed=47)
+    mel, lens = synth.synth_mel(3, 80, 131, seed=47).cuda(), torch.tensor([131, 90, 57])
+    tgt, tl = synth.synth_targets(3, 9, kw["dec_voc_size"], seed=47)
+    exit_ctc_losses(gpu(mel, lens), tgt, tl).sum().backward()
+    plain = {n: p.grad.clone() for n, p in gpu.named_parameters()}
+    gpu.zero_grad(set_to_none=True)
+    for m in gpu.modules():  # the same batch statistics again: reset what the first step updated
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.reset_running_stats()
+    gpu.enable_data_parallel(3, min_bucket_bytes=0)  # one bucket per exit group even on this small model
+    exit_ctc_losses(gpu(mel, lens), tgt, tl).sum().backward()
+    assert gpu.sync_gradients() == 0
+    gb = gpu._dp["buckets"]
+    assert [b["ready_after"] for b in gb.buckets][-1] == -1 and len(gb.buckets) >= 2
+    for n, p in gpu.named_parameters():
+        assert p.grad.data_ptr() == gb.view(n, p).data_ptr(), n
+        assert torch.equal(p.grad, plain[n]), n
+    exit_ctc_losses(gpu(mel, lens), tgt, tl).sum().backward()  # accumulates (autograd semantics), views untouched by the kernels
+    for n, p in gpu.named_parameters():
+        assert torch.allclose(p.grad, 2 * plain[n], rtol=1e-5, atol=1e-7), n
+
+
 @pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2)], ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention"])
 def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     """drop_prob > 0: streams cannot match torch's, so the check is internal -- the same seed reproduces the step, another
@@ -183,9 +261,115 @@ def test_train_mode_without_autograd_keeps_train_semantics():
     assert (ev - without).abs().max().item() > 1e-3
 
 
+ref_decode = ref_decoder_logits  # the reference's decoder arithmetic through the torch modules (tests/conftest.py), CPU side only
+
+
+def make_aed_pair(kw, common, seed):
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    import aed_fixture as G
+    gpu = full_conformer(device="cuda", **common, **kw)
+    sd = G.aed_state_dict(gpu, seed)
+    gpu.load_state_dict(sd, strict=True)
+    cpu = full_conformer(device="cpu", **common, **kw)
+    cpu.load_state_dict(sd, strict=True)
+    return cpu.train(), gpu.cuda().train(), sd
+
+
+@pytest.mark.parametrize("B,S,Tq,n_dec,d_model,n_head", [(3, 7, 31, 2, 256, 8), (4, 42, 64, 3, 256, 8), (2, 19, 40, 2, 128, 2), (5, 1, 9, 1, 64, 4)])
+def test_decoder_training_step_matches_reference_modules(B, S, Tq, n_dec, d_model, n_head):
+    """The AED decoder alone (eec_decoder_train_forward / _backward behind model._decode_one in train mode) against torch autograd
+    through the reference's modules on the CPU, drop_prob 0: logits, the gradient of every decoder parameter (embedding table and
+    the shared final LayerNorm included) and the gradient of the encoder output it attended to; padded target positions, head
+    dims 32 / 64 / 16, a single-token prefix."""
+    kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=d_model, n_head=n_head, d_feed_forward=192, depthwise_kernel_size=7, dec_voc_size=64)
+    common = dict(trg_pad_idx=30, enc_voc_size=64, max_len=400, features_length=80, drop_prob=0.0, n_dec_layers=n_dec)
+    cpu, gpu, _ = make_aed_pair(kw, common, seed=13)
+    g = torch.Generator().manual_seed(B * 100 + S)
+    trg = torch.randint(3, 64, (B, S), generator=g)
+    trg[:, 0] = 1
+    if S > 4:
+        trg[1, S - 3:] = 30  # padding at the end of one target
+    enc = torch.randn(B, Tq, d_model, generator=g)
+    w = torch.randn(B, S, 64, generator=g)  # a fixed linear functional of the logits as the loss
+    for idx in (1, 0):
+        e_ref = enc.clone().requires_grad_(True)
+        want = ref_decode(cpu, trg, e_ref, idx)
+        cpu.zero_grad()
+        (want * w).sum().backward()
+        e_gpu = enc.cuda().requires_grad_(True)
+        got = gpu._decode_one(trg.cuda(), e_gpu, idx)
+        assert got.requires_grad and got.shape == want.shape
+        err = (got.detach().cpu() - want.detach()).abs().max().item()
+        assert err < 2e-4 * max(1.0, want.detach().abs().max().item()), err
+        gpu.zero_grad()
+        (got * w.cuda()).sum().backward()
+        wantg = {n: p.grad.double() for n, p in cpu.named_parameters() if p.grad is not None}
+        gotg = {n: p.grad.detach().cpu().double() for n, p in gpu.named_parameters() if p.grad is not None}
+        assert set(wantg) == set(gotg), sorted(set(wantg) ^ set(gotg))[:5]
+        compare_grads(gotg, wantg, 2e-3, f"decoder {idx} bf16x3")
+        ge, gw = e_gpu.grad.cpu(), e_ref.grad
+        assert (ge - gw).abs().max().item() < 2e-3 * gw.abs().max().item(), "gradient of the encoder output"
+
+
+def test_decoder_dropout_masks_are_consistent_between_forward_and_backward():
+    """drop_prob > 0: torch's streams cannot match, so the check is internal -- one seed reproduces the logits, another changes
+    them, eval-mode inference is untouched, and the analytic gradient equals a central finite difference of the SAME masked
+    network along a random direction in (parameter, encoder-output) space."""
+    kw = dict(n_enc_exits=2, n_enc_layers=1, d_model=128, n_head=4, d_feed_forward=160, depthwise_kernel_size=7, dec_voc_size=64)
+    common = dict(trg_pad_idx=30, enc_voc_size=64, max_len=400, features_length=80, drop_prob=0.1, n_dec_layers=2)
+    _, gpu, _ = make_aed_pair(kw, common, seed=17)
+    g = torch.Generator().manual_seed(5)
+    trg = torch.randint(3, 64, (3, 9), generator=g).cuda()
+    enc = torch.randn(3, 21, 128, generator=g).cuda()
+    w = torch.randn(3, 9, 64, generator=g).cuda()
+    named = gpu._decoder_named_params(1)
+
+    def f(seed, e=enc):
+        return (gpu._decode_one(trg, e, 1, seed=seed) * w).mean()
+
+    a, b, c = f(7).item(), f(7).item(), f(8).item()
+    assert a == b and abs(a - c) > 1e-6 * abs(a)  # one seed reproduces the masked network, another draws other masks
+    gpu.dropout = 0.0
+    a0 = f(7).item()
+    gpu.dropout = 0.1
+    assert abs(a - a0) > 1e-6 * abs(a0)  # dropout is active
+    e = enc.clone().requires_grad_(True)
+    gpu.zero_grad()
+    f(7, e).backward()
+    params = dict(named)
+    gen = torch.Generator().manual_seed(0)
+    names = ["emb.weight", "decoders.1.layers.0.self_attn.in_proj_weight", "decoders.1.layers.1.multihead_attn.in_proj_weight",
+             "decoders.1.layers.0.linear1.weight", "decoders.1.layers.1.linear2.weight", "decoders.1.layers.1.norm2.weight",
+             "layer_norm.bias", "linears_2.1.weight", "<enc>"]
+    for n in names:
+        p = enc if n == "<enc>" else params[n]
+        grad = e.grad if n == "<enc>" else p.grad
+        d = torch.randn(p.shape, generator=gen).cuda()
+        d = d / d.norm()
+        eps = 2e-2
+        if n == "<enc>":
+            lp, lm = f(7, enc + eps * d).item(), f(7, enc - eps * d).item()
+        else:
+            with torch.no_grad():
+                p.add_(eps * d)
+            lp = f(7).item()
+            with torch.no_grad():
+                p.sub_(2 * eps * d)
+            lm = f(7).item()
+            with torch.no_grad():
+                p.add_(eps * d)
+        fd = (lp - lm) / (2 * eps)
+        an = (grad * d).sum().item()
+        print(f"\n[decoder dropout grad check] {n}: analytic {an:.5e}  finite difference {fd:.5e}")
+        assert abs(fd - an) < 0.05 * max(abs(an), abs(fd)) + 2e-3, n
+
+
 def test_aed_training_step_matches_reference_modules():
-    """train.py:36-52 (decoder_mode aed) on full_conformer: encoder forward / backward on the HIP training kernels (the taps it
-    hands to the decoders are differentiable outputs of the same autograd function), decoders on PyTorch-ROCm autograd.
+    """train.py:36-52 (decoder_mode aed) on full_conformer, everything on the HIP training kernels: the encoder's forward /
+    backward (the taps it hands to the decoders are differentiable outputs of the same autograd function) and the decoders'
+    (csrc/decoder_train.hip; no torch module runs under autograd -- checked by making their forward raise).
     Against the same parameters run through the oracle encoder + the reference's decoder modules on the CPU (drop_prob 0):
     CTC log-probs, decoder logits and the gradient of every parameter."""
     import os
@@ -219,10 +403,14 @@ def test_aed_training_step_matches_reference_modules():
     hooks = [m.register_forward_hook(lambda _m, _i, o: taps.append(o[0] if isinstance(o, tuple) else o)) for m in ref_enc.conformer]
     want_enc = ref_enc(mel, lens)
     [h.remove() for h in hooks]
-    want_dec = torch.stack([cpu._decode_one(trg[:, :-1], taps[e], e) for e in range(2)])
+    want_dec = torch.stack([ref_decode(cpu, trg[:, :-1], taps[e], e) for e in range(2)])
     want_loss = R.summed_exit_ctc_loss(want_enc, tgt, tl) + sum(ce(want_dec[e].reshape(-1, 64), trg[:, 1:].reshape(-1)) for e in range(2))
     want_loss.backward()
 
+    def no_torch_decoder(*_a, **_k):
+        raise AssertionError("a torch decoder module ran under autograd: the training step must stay on the HIP path")
+    for m in list(gpu.decoders) + [gpu.emb, gpu.layer_norm] + list(gpu.linears_2):
+        m.forward = no_torch_decoder
     dec_out, enc_out = gpu(mel.cuda(), lens, trg[:, :-1].cuda())
     assert (enc_out.detach().cpu() - want_enc.detach()).abs().max().item() < 2e-4
     assert (dec_out.detach().cpu() - want_dec.detach()).abs().max().item() < 2e-3

@@ -8,7 +8,7 @@ name=$1; defs=$2; shift 2
 cd "$(dirname "$0")/../early_exit_transformer_amd/csrc"
 [ -f build/capi.o ] || make -s -j6
 objs=""
-for s in capi ffn linear attention conv stem ctc pack frontend ctc_beam train_kernels train_attention train decoder decoder_step; do
+for s in capi ffn linear attention conv stem ctc pack frontend ctc_beam train_kernels train_attention train decoder decoder_step decoder_train; do
   if [[ " $* " == *" $s.hip "* ]]; then
     extra=""
     if [ "$s" = ffn ] && [ "${EEC_FULL:-0}" != 1 ]; then extra="-DEEC_CHAIN_MINIMAL"; fi
