@@ -90,6 +90,9 @@ EXPORTS = ["eec_last_error", "eec_abi_version", "eec_out_frames", "eec_encoder_c
            "eec_frontend_last_error", "eec_frontend_create", "eec_frontend_destroy", "eec_frontend_frames", "eec_frontend_forward",
            "eec_trainer_last_error", "eec_trainer_create", "eec_trainer_destroy", "eec_trainer_workspace_bytes",
            "eec_train_forward", "eec_train_backward", "eec_train_backward_ex", "eec_train_gemm",
+           "eec_train_group_workspace_bytes", "eec_train_group_forward", "eec_train_group_backward", "eec_train_stem_workspace_bytes",
+           "eec_train_stem_forward", "eec_train_stem_backward", "eec_train_head_forward", "eec_train_head_backward_scratch_floats",
+           "eec_train_head_backward",
            "eec_decoder_last_error", "eec_decoder_workspace_bytes", "eec_decoder_forward",
            "eec_decoder_train_last_error", "eec_decoder_train_workspace_bytes", "eec_decoder_train_forward", "eec_decoder_train_backward",
            "eec_decoder_step_last_error", "eec_decoder_step_max_beams", "eec_decoder_cache_bytes", "eec_decoder_begin", "eec_decoder_step", "eec_decoder_step_multi", "eec_upload_i64_max", "eec_upload_i64", "eec_beam_select"]
@@ -164,6 +167,24 @@ def load() -> C.CDLL:
                                        C.c_void_p, C.c_size_t, C.c_void_p]
     lib.eec_train_backward_ex.argtypes = [C.c_void_p, C.POINTER(EecParams), C.POINTER(EecParams), C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p, GROUP_DONE_FN, C.c_void_p]
+    lib.eec_train_group_workspace_bytes.argtypes = [C.POINTER(EecConfig), C.c_int, C.c_int, C.c_int]
+    lib.eec_train_group_workspace_bytes.restype = C.c_size_t
+    lib.eec_train_group_forward.argtypes = [C.POINTER(EecConfig), C.POINTER(EecLayerParams), C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
+                                            C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_group_backward.argtypes = [C.POINTER(EecConfig), C.POINTER(EecLayerParams), C.POINTER(EecLayerParams), C.c_int, C.c_void_p,
+                                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_stem_workspace_bytes.argtypes = [C.POINTER(EecConfig), C.c_int, C.c_int, C.c_int]
+    lib.eec_train_stem_workspace_bytes.restype = C.c_size_t
+    lib.eec_train_stem_forward.argtypes = [C.POINTER(EecConfig), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_stem_backward.argtypes = [C.POINTER(EecConfig), C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.eec_train_head_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.eec_train_head_backward_scratch_floats.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.eec_train_head_backward_scratch_floats.restype = C.c_size_t
+    lib.eec_train_head_backward.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p]
     lib.eec_decoder_last_error.restype = C.c_char_p

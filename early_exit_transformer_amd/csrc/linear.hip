@@ -158,7 +158,8 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   constexpr float kNegBig = -1.0e30f;
   const int lane = lane_id(), w = wave_id(), r = lane & 31, hh = lane >> 5;
   const int b = row0 / a.Tq, q0 = row0 - b * a.Tq, bh = b * a.H + w;
-  const int len = min(a.enc_len[b], a.Tq);
+  const int len_raw = a.enc_len[b];  // requested first, consumed after the first K / V requests have left
+  int len = 0, nkt = 0;
   const bool v2 = a.vt_lo != nullptr;  // uniform
   h8 qf[MT][KSQ];
 #pragma unroll
@@ -180,15 +181,18 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
   const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
   const half_t* vlbase = v2 ? a.vt_lo + (size_t)bh * DH * a.Tp : vbase;
-  const int nkt = (len + 31) / 32;
   struct Blk {  // K and V^T fragments of one block of KB key tiles
     h8 k[KB][KSQ], v[KB][DT][2], vl[KB][DT][2];
   };
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-  auto fetch = [&](Blk& f, int kt0) {
+  // `last`: the last tile that may be read (a tile past the utterance's keys is re-read and masked away below).  The FIRST
+  // block is fetched against the padded frame count, which is a kernel argument: its requests leave together with the Q
+  // fragments', before the utterance's length has arrived (a dependent load: ~2 us at kernel start, measured 7 k cycles from
+  // kernel entry to the first K / V request)
+  auto fetch = [&](Blk& f, int kt0, int last) {
 #pragma unroll
     for (int j = 0; j < KB; ++j) {
-      const int kt = min(kt0 + j, nkt - 1);  // a tile past the end is re-read and masked away below
+      const int kt = min(kt0 + j, last);
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) f.k[j][ks] = *(const h8*)(kbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
 #pragma unroll
@@ -260,18 +264,33 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
     }
   };
   Blk fa, fb;
-  if (nkt > 0) fetch(fa, 0);
+#ifdef EEC_ATTN_LATE_FETCH  // A/B knob: the round-2 order (first fetch behind the length)
+  len = min(len_raw, a.Tq);
+  nkt = (len + 31) / 32;
+  if (nkt > 0) fetch(fa, 0, nkt - 1);
+#else
+  fetch(fa, 0, a.Tp / 32 - 1);
+  __builtin_amdgcn_sched_barrier(0);
+  len = min(len_raw, a.Tq);
+  nkt = (len + 31) / 32;
+#endif
+#ifdef EEC_ATTN_PRIO  // A/B knob: static priority for the younger half of the workgroup (waves 4-7 lose every issue arbitration)
+  if (w >= 4) __builtin_amdgcn_s_setprio(EEC_ATTN_PRIO);
+#endif
   EEC_TL_STAMP(glu, 11);
   for (int kt0 = 0; kt0 < nkt; kt0 += 2 * KB) {
-    if (kt0 + KB < nkt) fetch(fb, kt0 + KB);
+    if (kt0 + KB < nkt) fetch(fb, kt0 + KB, nkt - 1);
     block(fa, kt0);
     EEC_TL_STAMP(glu, kt0 == 0 ? 12 : 14);
     if (kt0 + KB < nkt) {
-      if (kt0 + 2 * KB < nkt) fetch(fa, kt0 + 2 * KB);
+      if (kt0 + 2 * KB < nkt) fetch(fa, kt0 + 2 * KB, nkt - 1);
       block(fb, kt0 + KB);
     }
     EEC_TL_STAMP(glu, kt0 == 0 ? 13 : 15);
   }
+#ifdef EEC_ATTN_PRIO
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // normalise and write the planes.  No valid key at all (length 0): the installed torch returns zeros ("safe softmax").
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {

@@ -635,6 +635,301 @@ int eec_train_backward_ex(eec_trainer* tr, const eec_params* params, const eec_p
   return 0;
 }
 
+// ---- Building blocks of the training step (the other model types of train.py:180-208: Splitformer, Early_zipformer) ---------
+// The same forward / backward modules as the monolithic step above, cut at the places where those models put their own glue
+// (strided slices, repeats, adds: torch ops under autograd): a GROUP of Conformer layers on given rows, the STEM (one or two
+// convolutions + positional encoding) and an exit HEAD.  The entries are stateless: the recorded activations live in the
+// caller's workspace, whose layout is a function of the geometry, so the backward re-derives the pointers by a dry run of the
+// forward's carve (same seed / drop_prob / site_base regenerate the masks).  Everything runs on the caller's stream.
+}  // extern "C"
+
+namespace {
+
+struct BlockSizes {
+  size_t tape, fwd_scr, bwd_tape, bwd_scr, side;
+  size_t total() const { return tape + std::max(fwd_scr, bwd_tape + side + bwd_scr) + 1024; }
+};
+size_t up256(size_t n) { return (n + 255) / 256 * 256; }
+
+void group_forward(Run& r, const eec_layer_params* layers, int n_layers, const float* x_in, float* x_out, float* bn_mv) {
+  eec_trainer* tr = r.tr;
+  const int M = tr->M, D = tr->cfg.d_model;
+  tr->lt.assign(n_layers, LayerTape{});
+  float* x = (float*)x_in;
+  static const eec_layer_params kNone{};
+  for (int l = 0; l < n_layers; ++l) {
+    const eec_layer_params& L = layers ? layers[l] : kNone;
+    LayerTape& t = tr->lt[l];
+    x = ffn_fwd(r, t.f1, x, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1, L.ffn1_b1, L.ffn1_w2, L.ffn1_b2);
+    x = attn_fwd(r, t.at, x, L);
+    x = conv_fwd(r, t.cv, x, L, bn_mv ? bn_mv + (size_t)l * 2 * D : nullptr);
+    x = ffn_fwd(r, t.f2, x, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1, L.ffn2_b1, L.ffn2_w2, L.ffn2_b2);
+    t.x4 = x, t.fmean = r.tape.f(M), t.frstd = r.tape.f(M), t.out = r.tape.f((size_t)M * D);
+    RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
+    x = t.out;
+  }
+  if (x_out) RUN(hipMemcpyAsync(x_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+}
+void group_backward(Run& r, const eec_layer_params* layers, const eec_layer_params* grads, int n_layers, const float* grad_out, float* grad_in) {
+  eec_trainer* tr = r.tr;
+  const int M = tr->M, D = tr->cfg.d_model;
+  float* dx = r.tape.f((size_t)M * D);
+  if (grad_out) RUN(hipMemcpyAsync(dx, grad_out, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+  static const eec_layer_params kNone{};
+  for (int l = n_layers - 1; l >= 0; --l) {
+    const eec_layer_params& L = layers ? layers[l] : kNone;
+    eec_layer_params G = grads ? grads[l] : kNone;
+    const LayerTape& t = tr->lt[l];
+    ln_bwd(r, dx, t.x4, L.final_ln_w, t.fmean, t.frstd, dx, false, (float*)G.final_ln_w, (float*)G.final_ln_b, M, D);
+    ffn_bwd(r, t.f2, dx, L.ffn2_ln_w, L.ffn2_w1, L.ffn2_w2, (float*)G.ffn2_ln_w, (float*)G.ffn2_ln_b, (float*)G.ffn2_w1, (float*)G.ffn2_b1,
+            (float*)G.ffn2_w2, (float*)G.ffn2_b2);
+    conv_bwd(r, t.cv, dx, L, G);
+    attn_bwd(r, t.at, dx, L, G);
+    ffn_bwd(r, t.f1, dx, L.ffn1_ln_w, L.ffn1_w1, L.ffn1_w2, (float*)G.ffn1_ln_w, (float*)G.ffn1_ln_b, (float*)G.ffn1_w1, (float*)G.ffn1_b1,
+            (float*)G.ffn1_w2, (float*)G.ffn1_b2);
+  }
+  join_side(r);
+  if (grad_in) RUN(hipMemcpyAsync(grad_in, dx, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
+}
+BlockSizes group_sizes(eec_trainer tmp, int n_layers) {
+  Run d{&tmp, true, nullptr};
+  group_forward(d, nullptr, n_layers, nullptr, nullptr, nullptr);
+  BlockSizes z{};
+  z.tape = up256(d.tape.peak), z.fwd_scr = up256(d.scr.peak);
+  Run b{&tmp, true, nullptr};
+  group_backward(b, nullptr, nullptr, n_layers, nullptr, nullptr);
+  z.bwd_tape = up256(b.tape.peak), z.bwd_scr = up256(b.scr.peak), z.side = up256(b.sscr.peak);
+  return z;
+}
+int block_trainer(eec_trainer& tr, const eec_config* cfg, int B, int Tq, int passes, float drop_prob, uint64_t seed, const int32_t* key_len) {
+  if (!cfg) return tfail(EEC_ERR_BAD_ARG, "null argument");
+  if (int rc = check_trainer_cfg(*cfg)) return rc;
+  if (passes != 1 && passes != 3) return tfail(EEC_ERR_BAD_ARG, "passes: 1 (bf16) or 3 (bf16x3)");
+  if (!(drop_prob >= 0.0f && drop_prob < 1.0f)) return tfail(EEC_ERR_BAD_ARG, "drop_prob in [0, 1)");
+  if (B <= 0 || Tq <= 0 || Tq > cfg->max_len) return tfail(EEC_ERR_BAD_ARG, "B >= 1, 1 <= T' <= max_len");
+  tr.cfg = *cfg;
+  tr.B = B, tr.Tq = Tq, tr.M = B * Tq, tr.np = passes, tr.p = drop_prob, tr.seed = seed, tr.key_len = (int32_t*)key_len;
+  return 0;
+}
+
+// stem: Conv1d(k3, s2) [-> Conv1d(k3, s2)] -> + positional encoding -> dropout; x [B][To][D], To = T1 (one conv) or T' (two)
+struct StemGeo {
+  int B, C, T, T1, To, D;
+  bool two;
+};
+struct StemTape {
+  float *a1, *out1, *w2p;
+};
+StemTape stem_carve(Bump& t, const StemGeo& g) {
+  StemTape s{};
+  s.a1 = t.f((size_t)g.B * g.T1 * 3 * g.C);
+  if (g.two) s.out1 = t.f((size_t)g.B * g.T1 * g.D), s.w2p = t.f((size_t)g.D * 3 * g.D);
+  return s;
+}
+void stem_forward(Run& r, const StemGeo& g, const float* w0, const float* b0, const float* w1, const float* b1, const float* pe, const float* mel,
+                  float* x, uint32_t site) {
+  const StemTape s = stem_carve(r.tape, g);
+  RUN(launch_im2col_mel(mel, s.a1, g.B, g.C, g.T, g.T1, r.st));
+  if (g.two) {
+    linear_fwd(r, s.a1, w0, b0, s.out1, g.B * g.T1, g.D, 3 * g.C);
+    RUN(launch_permute_w3(w1, s.w2p, g.D, g.D, 1, r.st));
+    GemmArgs a = gemm_args(s.out1, 2 * g.D, 1, s.w2p, 3 * g.D, 1, x, g.D, g.To, g.D, 3 * g.D);
+    a.bias = b1, a.nz = g.B, a.zdiv = 1, a.a_z0 = (long)g.T1 * g.D, a.c_z0 = (long)g.To * g.D;
+    RUN(launch_gemm(a, r.tr->np, r.st));
+  } else {
+    linear_fwd(r, s.a1, w0, b0, x, g.B * g.T1, g.D, 3 * g.C);
+  }
+  RUN(launch_add_pe_drop(x, pe, g.B, g.To, g.D, drop_of(r, site), r.st));
+}
+void stem_backward(Run& r, const StemGeo& g, const float* grad_x, float* g_w0, float* g_b0, float* g_w1, float* g_b1, uint32_t site) {
+  const StemTape s = stem_carve(r.tape, g);
+  const int B = g.B, D = g.D, T1 = g.T1, To = g.To, M = B * To;
+  r.scr.reset();
+  float* dx0 = r.scr.f((size_t)M * D);
+  RUN(launch_scale_drop(grad_x, 1.0f, dx0, (long)M * D, drop_of(r, site), r.st));
+  if (!g.two) {
+    linear_bwd_weight(r, dx0, s.a1, g_w0, g_b0, M, D, 3 * g.C);
+    join_side(r);
+    return;
+  }
+  float* Gc = r.scr.f((size_t)M * 3 * D);
+  float* dout1 = r.scr.f((size_t)B * T1 * D);
+  float* dw2p = r.scr.f((size_t)D * 3 * D);
+  {
+    const size_t mark = r.scr.off;
+    float* part = r.scr.f((size_t)B * D * 3 * D);
+    GemmArgs a = gemm_args(dx0, 1, D, s.out1, 1, 2 * D, part, 3 * D, D, 3 * D, To);
+    a.nz = B, a.zdiv = 1, a.a_z0 = (long)To * D, a.b_z0 = (long)T1 * D, a.c_z0 = (long)D * 3 * D;
+    RUN(launch_gemm(a, r.tr->np, r.st));
+    RUN(launch_reduce_leading(part, B, (long)D * 3 * D, (long)D * 3 * D, dw2p, r.st));
+    RUN(launch_permute_w3(dw2p, g_w1, D, D, 0, r.st));
+    r.scr.reset(mark);
+    const int nb = colsum_blocks(M);
+    float* bpart = r.scr.f((size_t)nb * D);
+    RUN(launch_colsum_partial(dx0, M, D, bpart, r.st));
+    RUN(launch_reduce_leading(bpart, nb, D, D, g_b1, r.st));
+    r.scr.reset(mark);
+  }
+  {  // G[m][(j, c)] = sum_o dx0[m][o] w2p[o][(j, c)]
+    GemmArgs a = gemm_args(dx0, D, 1, s.w2p, 1, 3 * D, Gc, 3 * D, M, 3 * D, D);
+    RUN(launch_gemm(a, r.tr->np, r.st));
+  }
+  RUN(launch_col2im_stride2(Gc, dout1, B, T1, To, D, r.st));
+  linear_bwd_weight(r, dout1, s.a1, g_w0, g_b0, B * T1, D, 3 * g.C);
+  join_side(r);
+}
+int stem_geo(StemGeo& g, const eec_config* cfg, int B, int T, int two) {
+  if (!cfg || B <= 0 || T < (two ? 7 : 3)) return tfail(EEC_ERR_BAD_ARG, "B >= 1 and T >= 3 (one convolution) / 7 (two)");
+  const int T1 = (T - 3) / 2 + 1;
+  g = StemGeo{B, cfg->n_mels, T, T1, two ? (T1 - 3) / 2 + 1 : T1, cfg->d_model, two != 0};
+  if (g.To > cfg->max_len) return tfail(EEC_ERR_BAD_ARG, "output frames exceed max_len");
+  return 0;
+}
+struct StemSizes {
+  size_t tape, scr, side;
+};
+StemSizes stem_sizes(eec_trainer tmp, const StemGeo& g) {
+  Run d{&tmp, true, nullptr};
+  stem_backward(d, g, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+  return StemSizes{up256(d.tape.peak), up256(d.scr.peak), up256(d.sscr.peak)};
+}
+int finish(const Run& r) {
+  if (r.tape.overflow || r.scr.overflow || r.sscr.overflow) return tfail(EEC_ERR_WORKSPACE, "internal: workspace carve exceeded its size");
+  if (r.err != hipSuccess) return tfail((int)r.err, std::string(r.where) + ": " + hipGetErrorString(r.err));
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t eec_train_group_workspace_bytes(const eec_config* cfg, int n_layers, int B, int Tq) {
+  eec_trainer tmp;
+  if (n_layers <= 0 || n_layers > 64 || block_trainer(tmp, cfg, B, Tq, 3, 0.0f, 0, nullptr)) return 0;
+  return group_sizes(tmp, n_layers).total();
+}
+
+int eec_train_group_forward(const eec_config* cfg, const eec_layer_params* layers, int n_layers, const float* x_in, const int32_t* key_len, int B,
+                            int Tq, int passes, float drop_prob, uint64_t seed, uint32_t site_base, float* x_out, float* bn_batch_stats,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+  if (!layers || !x_in || !key_len || !x_out || !workspace || n_layers <= 0 || n_layers > 64) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  if (((uintptr_t)workspace & 255) != 0) return tfail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  eec_trainer tr;
+  if (int rc = block_trainer(tr, cfg, B, Tq, passes, drop_prob, seed, key_len)) return rc;
+  const BlockSizes z = group_sizes(tr, n_layers);
+  if (workspace_bytes < z.total()) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  Run r{&tr, false, (hipStream_t)stream};
+  r.site = site_base;
+  r.tape.base = (char*)workspace, r.tape.cap = z.tape;
+  r.scr.base = (char*)workspace + z.tape, r.scr.cap = workspace_bytes - z.tape;
+  group_forward(r, layers, n_layers, x_in, x_out, bn_batch_stats);
+  return finish(r);
+}
+
+int eec_train_group_backward(const eec_config* cfg, const eec_layer_params* layers, const eec_layer_params* grads, int n_layers, const float* x_in,
+                             const int32_t* key_len, int B, int Tq, int passes, float drop_prob, uint64_t seed, uint32_t site_base,
+                             const float* grad_out, float* grad_in, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!layers || !grads || !x_in || !key_len || !grad_out || !grad_in || !workspace || n_layers <= 0 || n_layers > 64)
+    return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  if (((uintptr_t)workspace & 255) != 0) return tfail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  eec_trainer tr;
+  if (int rc = block_trainer(tr, cfg, B, Tq, passes, drop_prob, seed, key_len)) return rc;
+  const BlockSizes z = group_sizes(tr, n_layers);
+  if (workspace_bytes < z.total()) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  {  // the recorded tape's pointers: the forward's carve again, without launches
+    Run d{&tr, true, nullptr};
+    d.site = site_base;
+    d.tape.base = (char*)workspace;
+    group_forward(d, layers, n_layers, x_in, nullptr, nullptr);
+  }
+  Run r{&tr, false, (hipStream_t)stream};
+  char* base = (char*)workspace + z.tape;
+  r.tape.base = base, r.tape.cap = z.bwd_tape;
+  r.sscr.base = base + z.bwd_tape, r.sscr.cap = z.side;
+  r.scr.base = base + z.bwd_tape + z.side, r.scr.cap = workspace_bytes - z.tape - z.bwd_tape - z.side;
+  group_backward(r, layers, grads, n_layers, grad_out, grad_in);
+  return finish(r);
+}
+
+size_t eec_train_stem_workspace_bytes(const eec_config* cfg, int B, int T, int two_convs) {
+  StemGeo g;
+  eec_trainer tmp;
+  if (stem_geo(g, cfg, B, T, two_convs) || block_trainer(tmp, cfg, B, g.To, 3, 0.0f, 0, nullptr)) return 0;
+  const StemSizes z = stem_sizes(tmp, g);
+  return z.tape + z.scr + z.side + 1024;
+}
+
+int eec_train_stem_forward(const eec_config* cfg, const float* sub0_w, const float* sub0_b, const float* sub1_w, const float* sub1_b,
+                           const float* pe, const float* mel, int B, int T, int passes, float drop_prob, uint64_t seed, uint32_t site, float* x_out,
+                           void* workspace, size_t workspace_bytes, void* stream) {
+  if (!sub0_w || !sub0_b || !pe || !mel || !x_out || !workspace || (sub1_w != nullptr) != (sub1_b != nullptr)) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  if (((uintptr_t)workspace & 255) != 0) return tfail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  StemGeo g;
+  if (int rc = stem_geo(g, cfg, B, T, sub1_w != nullptr)) return rc;
+  eec_trainer tr;
+  if (int rc = block_trainer(tr, cfg, B, g.To, passes, drop_prob, seed, nullptr)) return rc;
+  const StemSizes z = stem_sizes(tr, g);
+  if (workspace_bytes < z.tape + z.scr + z.side) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  Run r{&tr, false, (hipStream_t)stream};
+  r.tape.base = (char*)workspace, r.tape.cap = z.tape;
+  r.scr.base = (char*)workspace + z.tape, r.scr.cap = workspace_bytes - z.tape;
+  stem_forward(r, g, sub0_w, sub0_b, sub1_w, sub1_b, pe, mel, x_out, site);
+  return finish(r);
+}
+
+int eec_train_stem_backward(const eec_config* cfg, int two_convs, int B, int T, int passes, float drop_prob, uint64_t seed, uint32_t site,
+                            const float* grad_x, float* g_sub0_w, float* g_sub0_b, float* g_sub1_w, float* g_sub1_b, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!grad_x || !g_sub0_w || !g_sub0_b || !workspace || (two_convs && (!g_sub1_w || !g_sub1_b))) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  if (((uintptr_t)workspace & 255) != 0) return tfail(EEC_ERR_WORKSPACE, "workspace must be 256-byte aligned");
+  StemGeo g;
+  if (int rc = stem_geo(g, cfg, B, T, two_convs)) return rc;
+  eec_trainer tr;
+  if (int rc = block_trainer(tr, cfg, B, g.To, passes, drop_prob, seed, nullptr)) return rc;
+  const StemSizes z = stem_sizes(tr, g);
+  if (workspace_bytes < z.tape + z.scr + z.side) return tfail(EEC_ERR_WORKSPACE, "workspace too small");
+  Run r{&tr, false, (hipStream_t)stream};
+  r.tape.base = (char*)workspace, r.tape.cap = z.tape;
+  r.sscr.base = (char*)workspace + z.tape, r.sscr.cap = z.side;
+  r.scr.base = (char*)workspace + z.tape + z.side, r.scr.cap = workspace_bytes - z.tape - z.side;
+  stem_backward(r, g, grad_x, g_sub0_w, g_sub0_b, g_sub1_w, g_sub1_b, site);
+  return finish(r);
+}
+
+/* exit head: logp = log_softmax(x . W^T + b); scratch = M * V floats */
+int eec_train_head_forward(const float* x, const float* W, const float* b, int M, int V, int D, int passes, float* logp, float* scratch, void* stream) {
+  if (!x || !W || !b || !logp || !scratch || M <= 0 || V <= 0 || D <= 0 || (passes != 1 && passes != 3)) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  GemmArgs g = gemm_args(x, D, 1, W, D, 1, scratch, V, M, V, D);
+  g.bias = b;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipError_t e = launch_gemm(g, passes, st); e != hipSuccess) return tfail((int)e, hipGetErrorString(e));
+  if (hipError_t e = launch_logsoftmax_fwd(scratch, logp, M, V, st); e != hipSuccess) return tfail((int)e, hipGetErrorString(e));
+  return 0;
+}
+/* dx (optional) = dlogits . W, dW = dlogits^T . x, db = column sums of dlogits, with dlogits = grad_logp - exp(logp) * rowsum(grad_logp);
+ * scratch: eec_train_head_backward_scratch_floats(M, V, D) floats */
+size_t eec_train_head_backward_scratch_floats(int M, int V, int D) {
+  if (M <= 0 || V <= 0 || D <= 0) return 0;
+  eec_trainer tmp;
+  Run d{&tmp, true, nullptr};
+  linear_bwd_weight(d, nullptr, nullptr, nullptr, nullptr, M, V, D);
+  return (size_t)M * V + 64 + d.sscr.peak / sizeof(float) + 64;
+}
+int eec_train_head_backward(const float* x, const float* W, const float* logp, const float* grad_logp, int M, int V, int D, int passes, float* dx,
+                            float* dW, float* db, float* scratch, void* stream) {
+  if (!x || !W || !logp || !grad_logp || !dW || !db || !scratch || M <= 0 || D <= 0 || (passes != 1 && passes != 3)) return tfail(EEC_ERR_BAD_ARG, "bad argument");
+  if (V <= 0 || V > 256 || V % 4) return tfail(EEC_ERR_UNSUPPORTED, "the log-softmax backward needs vocab <= 256, a multiple of 4");
+  eec_trainer tr;
+  tr.np = passes;
+  Run r{&tr, false, (hipStream_t)stream};
+  float* dlogits = scratch;
+  r.sscr.base = (char*)(scratch + (((size_t)M * V + 63) / 64) * 64);
+  RUN(eec::launch_logsoftmax_backward(logp, grad_logp, M, V, dlogits, r.st));
+  linear_bwd_weight(r, dlogits, x, dW, db, M, V, D);
+  if (dx) linear_bwd_data(r, dlogits, W, dx, M, V, D);
+  return finish(r);
+}
+
 int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
                    int b_transposed, void* stream) {
   if (!A || !B || !C || (passes != 1 && passes != 3)) return tfail(EEC_ERR_BAD_ARG, "bad argument");

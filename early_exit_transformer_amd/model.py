@@ -356,6 +356,203 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         return [[tokens[e * B + b, : counts[e * B + b]].tolist() for b in range(B)] for e in range(E)]
 
 
+# ---- building blocks of the training step (Splitformer / Early_zipformer: train.py:180-208) ----------------------------------
+_GROUP_FIELDS = [f for f in capi._LAYER_FIELDS if f not in ("conv_bn_rm", "conv_bn_rv")]  # the 30 trainable tensors of a ConformerLayer
+
+
+def _group_layer_tensors(group: nn.Module) -> List[Tensor]:
+    """The parameters of a Conformer group, layer-major, in _GROUP_FIELDS order."""
+    out: List[Tensor] = []
+    for layer in group.conformer_layers:
+        sd = dict(layer.named_parameters())
+        out += [sd[capi.LAYER_KEYS[f]] for f in _GROUP_FIELDS]
+    return out
+
+
+def _group_struct(tensors: Sequence[Tensor], n_layers: int):
+    layers = (capi.EecLayerParams * n_layers)()
+    k = len(_GROUP_FIELDS)
+    for l in range(n_layers):
+        for i, f in enumerate(_GROUP_FIELDS):
+            setattr(layers[l], f, tensors[l * k + i].data_ptr())
+    return layers
+
+
+def _aligned_ws(nbytes: int, dev) -> Tuple[Tensor, int]:
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+    return ws, (ws.data_ptr() + 255) // 256 * 256
+
+
+class _TrainGroupFn(torch.autograd.Function):
+    """One Conformer group (torchaudio ``Conformer(num_layers=L)``: early_exit.py:160-172, 266-297) in train mode on rows
+    x [B, T', D] with key lengths key_len [B] (int32, device), and its backward, on the HIP training kernels
+    (eec_train_group_forward / _backward).  BatchNorm uses the batch statistics and updates the running ones like nn.BatchNorm1d."""
+
+    @staticmethod
+    def forward(ctx, model, group, x, key_len, seed, site_base, *params):
+        lib = capi.load()
+        dev = x.device
+        cfg = model._cfg
+        B, Tq, D = x.shape
+        L = len(group.conformer_layers)
+        for t in params:
+            if t.device != dev or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"group parameters must be contiguous fp32 tensors on {dev}")
+        x = x.contiguous().float()
+        with torch.cuda.device(dev):
+            layers = _group_struct(params, L)
+            nbytes = lib.eec_train_group_workspace_bytes(C.byref(cfg), L, B, Tq)
+            if nbytes == 0:
+                raise ValueError("unsupported geometry for a training group")
+            ws, ws_ptr = _aligned_ws(nbytes, dev)
+            out = torch.empty_like(x)
+            bn = torch.empty((L, 2, D), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_group_forward(C.byref(cfg), layers, L, x.data_ptr(), key_len.data_ptr(), B, Tq, int(model.train_passes),
+                                                       float(model.dropout), int(seed), int(site_base), out.data_ptr(), bn.data_ptr(), ws_ptr, nbytes,
+                                                       C.c_void_p(stream)), "eec_train_group_forward")
+            n = B * Tq
+            with torch.no_grad():
+                for l, layer in enumerate(group.conformer_layers):
+                    bnm = layer.conv_module.sequential[3]
+                    if bnm.track_running_stats and bnm.running_mean is not None:
+                        m = bnm.momentum if bnm.momentum is not None else 0.1
+                        bnm.running_mean.mul_(1 - m).add_(bn[l, 0], alpha=m)
+                        bnm.running_var.mul_(1 - m).add_(bn[l, 1] * (n / max(n - 1, 1)), alpha=m)
+                        bnm.num_batches_tracked += 1
+        ctx.model, ctx.L, ctx.seed, ctx.site_base = model, L, int(seed), int(site_base)
+        ctx.ws, ctx.ws_ptr, ctx.nbytes = ws, ws_ptr, nbytes
+        ctx.passes, ctx.drop = int(model.train_passes), float(model.dropout)
+        ctx.save_for_backward(x, key_len, *params)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        if ctx.ws is None:
+            raise RuntimeError("this group's recorded forward was already consumed by a backward")
+        x, key_len, params = ctx.saved_tensors[0], ctx.saved_tensors[1], ctx.saved_tensors[2:]
+        dev = x.device
+        lib = capi.load()
+        B, Tq, _ = x.shape
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            layers = _group_struct(params, ctx.L)
+            grads = [torch.empty_like(t) for t in params]
+            glayers = _group_struct(grads, ctx.L)
+            g_in = torch.empty_like(x)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_group_backward(C.byref(ctx.model._cfg), layers, glayers, ctx.L, x.data_ptr(), key_len.data_ptr(), B, Tq,
+                                                        ctx.passes, ctx.drop, ctx.seed, ctx.site_base, g.data_ptr(), g_in.data_ptr(), ctx.ws_ptr,
+                                                        ctx.nbytes, C.c_void_p(stream)), "eec_train_group_backward")
+        ctx.ws = None
+        need = ctx.needs_input_grad[6:]
+        return (None, None, g_in if ctx.needs_input_grad[2] else None, None, None, None, *[gr if nd else None for gr, nd in zip(grads, need)])
+
+
+class _TrainStemFn(torch.autograd.Function):
+    """Stem in train mode: Conv1d(k3, s2) [-> Conv1d(k3, s2)] -> + positional encoding -> dropout (early_exit.py:24-48 / 80-95,
+    positional_encoding.py:65-73) -> [B, To, D]; no gradient with respect to the mel input."""
+
+    @staticmethod
+    def forward(ctx, model, mel, pe, seed, site, w0, b0, w1, b1):
+        lib = capi.load()
+        dev = mel.device
+        cfg = model._cfg
+        B, _, T = mel.shape
+        two = w1 is not None
+        T1 = (T - 3) // 2 + 1
+        To = ((T1 - 3) // 2 + 1) if two else T1
+        with torch.cuda.device(dev):
+            nbytes = lib.eec_train_stem_workspace_bytes(C.byref(cfg), B, T, int(two))
+            if nbytes == 0:
+                raise ValueError("unsupported geometry for the training stem")
+            ws, ws_ptr = _aligned_ws(nbytes, dev)
+            out = torch.empty((B, To, cfg.d_model), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_stem_forward(C.byref(cfg), w0.data_ptr(), b0.data_ptr(), w1.data_ptr() if two else None,
+                                                      b1.data_ptr() if two else None, pe.data_ptr(), mel.data_ptr(), B, T, int(model.train_passes),
+                                                      float(model.dropout), int(seed), int(site), out.data_ptr(), ws_ptr, nbytes, C.c_void_p(stream)),
+                           "eec_train_stem_forward")
+        ctx.model, ctx.geo, ctx.two = model, (B, T), two
+        ctx.seed, ctx.site, ctx.passes, ctx.drop = int(seed), int(site), int(model.train_passes), float(model.dropout)
+        ctx.ws, ctx.ws_ptr, ctx.nbytes = ws, ws_ptr, nbytes
+        ctx.save_for_backward(mel, w0, b0, *((w1, b1) if two else ()))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        saved = ctx.saved_tensors
+        w0, b0 = saved[1], saved[2]
+        dev = g.device
+        lib = capi.load()
+        B, T = ctx.geo
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            g_w0, g_b0 = torch.empty_like(w0), torch.empty_like(b0)
+            g_w1 = torch.empty_like(saved[3]) if ctx.two else None
+            g_b1 = torch.empty_like(saved[4]) if ctx.two else None
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_stem_backward(C.byref(ctx.model._cfg), int(ctx.two), B, T, ctx.passes, ctx.drop, ctx.seed, ctx.site,
+                                                       g.data_ptr(), g_w0.data_ptr(), g_b0.data_ptr(), g_w1.data_ptr() if ctx.two else None,
+                                                       g_b1.data_ptr() if ctx.two else None, ctx.ws_ptr, ctx.nbytes, C.c_void_p(stream)),
+                           "eec_train_stem_backward")
+        ctx.ws = None
+        return (None, None, None, None, None, g_w0, g_b0, g_w1, g_b1)
+
+
+class _TrainHeadFn(torch.autograd.Function):
+    """Exit head ``log_softmax(x . W^T + b)`` (early_exit.py:629-631) and its backward on the training GEMM."""
+
+    @staticmethod
+    def forward(ctx, passes, x, W, b):
+        lib = capi.load()
+        dev = x.device
+        x = x.contiguous().float()
+        M, D = x.shape
+        V = W.size(0)
+        with torch.cuda.device(dev):
+            logp = torch.empty((M, V), dtype=torch.float32, device=dev)
+            scratch = torch.empty((M, V), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_head_forward(x.data_ptr(), W.data_ptr(), b.data_ptr(), M, V, D, int(passes), logp.data_ptr(),
+                                                      scratch.data_ptr(), C.c_void_p(stream)), "eec_train_head_forward")
+            scratch.record_stream(torch.cuda.current_stream(dev))
+        ctx.passes = int(passes)
+        ctx.save_for_backward(x, W, logp)
+        return logp
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        x, W, logp = ctx.saved_tensors
+        lib = capi.load()
+        dev = x.device
+        M, D = x.shape
+        V = W.size(0)
+        g = g.contiguous().float()
+        with torch.cuda.device(dev):
+            dW, db = torch.empty_like(W), torch.empty((V,), dtype=torch.float32, device=dev)
+            dx = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+            scratch = torch.empty((lib.eec_train_head_backward_scratch_floats(M, V, D),), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            _trainer_check(lib.eec_train_head_backward(x.data_ptr(), W.data_ptr(), logp.data_ptr(), g.data_ptr(), M, V, D, ctx.passes,
+                                                       dx.data_ptr() if dx is not None else None, dW.data_ptr(), db.data_ptr(), scratch.data_ptr(),
+                                                       C.c_void_p(stream)), "eec_train_head_backward")
+            scratch.record_stream(torch.cuda.current_stream(dev))
+        return (None, dx, dW, db)
+
+
+def _train_group(model, group: nn.Module, x: Tensor, key_len: Tensor, seed: int, site_base: int) -> Tensor:
+    return _TrainGroupFn.apply(model, group, x, key_len, seed, site_base, *_group_layer_tensors(group))
+
+
+def _train_head(model, linear: nn.Linear, x: Tensor) -> Tensor:
+    B, Tq, D = x.shape
+    return _TrainHeadFn.apply(model.train_passes, x.reshape(B * Tq, D), linear.weight, linear.bias).reshape(B, Tq, -1)
+
+
 class _TimeResample(nn.Module):
     """Parameterless stand-ins that keep the reference's module tree (Downsampling / Upsampling, early_exit.py:95-114)."""
 
@@ -428,7 +625,40 @@ class Splitformer(Early_conformer):
         capi.check(lib.eec_encoder_pack(self._par_enc, C.byref(params), C.c_void_p(stream)), "eec_encoder_pack")
         self._par_key = key
 
+    def _forward_training(self, src: Tensor, lengths: Tensor) -> Tensor:
+        """train.py:180-208 (--model_type splitformer) in train mode: every module on the HIP training kernels behind autograd
+        functions (stem, Conformer groups -- the E main ones and the two down-sampled branches --, heads); the strided slice, the
+        repeat and the add that glue the branches in are the same torch ops as in inference, differentiated by autograd."""
+        if not src.is_cuda:
+            raise RuntimeError("the MI355X training step runs on a HIP device only (there is no CPU fallback)")
+        dev = src.device
+        E = self._cfg.n_exits
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        conv = self.conv_subsample.sequential
+        x = _TrainStemFn.apply(self, src.contiguous().float(), self.positional_encoder.pe, seed, 1, conv[0].weight, conv[0].bias,
+                               conv[1].weight, conv[1].bias)
+        B, Tq, D = x.shape
+        mel_len = _to_device(lengths, dev)
+        base = torch.clamp(mel_len / 4, max=Tq).to(torch.int32)
+        outs = []
+        for index in range(E):
+            branch = index in (0, E - 1)
+            side = x
+            x = _train_group(self, self.conformer[index], x, base, seed, 16 + 128 * index)
+            if branch:
+                pad = (-Tq) % self.factor
+                if pad:
+                    side = torch.cat((side, side.new_zeros(B, pad, D)), dim=1)
+                side = side[:, :: self.factor, :].contiguous()
+                side_len = torch.clamp((mel_len + pad) / self.factor, max=side.size(1)).to(torch.int32)
+                side = _train_group(self, self.conformer_parallel[index // (E - 1)], side, side_len, seed, 16 + 128 * index + 64)
+                x = x + torch.repeat_interleave(side, self.factor, dim=1)[:, :Tq, :]
+            outs.append(_train_head(self, self.linears[index], x))
+        return torch.stack(outs)
+
     def forward(self, src: Tensor, lengths: Tensor) -> Tensor:
+        if self.training:
+            return self._forward_training(src, lengths)
         # stem (+ PE) through the monolithic entry's first sub-step; also validates src and packs the main handle
         x = self._run_encoder(src, lengths, want_out=False, stop_after=0, want_x=True)[2]
         dev = x.device
@@ -514,10 +744,10 @@ class Early_zipformer(_HipEncoderMixin, nn.Module):
         if not src.is_cuda:
             raise RuntimeError("the MI355X encoder runs on a HIP device only (there is no CPU fallback -- the CPU "
                                "reference lives in oracle/).")
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("Early_zipformer has no training step on the HIP path; call under model.eval() / torch.no_grad()")
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels or src.size(2) < 3:
             raise ValueError(f"src must be [B, {self._cfg.n_mels}, T >= 3], got {tuple(src.shape)}")
+        if self.training:
+            return self._forward_training(src, lengths)
         dev = src.device
         with torch.cuda.device(dev):
             self._ensure_packed(dev)
@@ -553,6 +783,38 @@ class Early_zipformer(_HipEncoderMixin, nn.Module):
             capi.check(rc, "eec_encoder_head_forward")
             src.record_stream(torch.cuda.current_stream(dev))
         return out
+
+
+def _zipformer_forward_training(self, src: Tensor, lengths: Tensor) -> Tensor:
+    """train.py:180-208 (--model_type zipformer) in train mode: one-convolution stem, the 19 Conformer groups at five frame rates
+    and the head on the HIP training kernels behind autograd functions; pad / stride / repeat / add are torch ops under autograd."""
+    dev = src.device
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    conv = self.conv_subsample.conv
+    enc = _TrainStemFn.apply(self, src.contiguous().float(), self.positional_encoder.pe, seed, 1, conv.weight, conv.bias, None, None)
+    B, T1, D = enc.shape
+    mel_len = _to_device(lengths, dev)
+    base = torch.clamp(mel_len / 2, max=T1).to(torch.int32)
+    enc = _train_group(self, self.conformer[0], enc, base, seed, 16)
+    enc = _train_group(self, self.conformer[1], enc, base, seed, 16 + 128)
+    first = 2
+    for factor, count in zip(self.factors, self.stack):
+        skip = enc
+        n = enc.size(1)
+        pad = (-n) % factor
+        if pad:
+            enc = torch.cat((enc, enc.new_zeros(B, pad, D)), dim=1)
+        enc = enc[:, ::factor, :].contiguous()
+        key_len = torch.clamp((mel_len + pad) / factor, max=enc.size(1)).to(torch.int32)
+        for g in range(first, first + count):
+            enc = _train_group(self, self.conformer[g], enc, key_len, seed, 16 + 128 * g)
+        first += count
+        enc = torch.repeat_interleave(enc, factor, dim=1)[:, :n, :] + skip
+    rows = enc[:, ::2, :].contiguous()
+    return _train_head(self, self.linear, rows).unsqueeze(0)
+
+
+Early_zipformer._forward_training = _zipformer_forward_training
 
 
 def encoder_lengths(lengths: Tensor, t_out: int) -> Tensor:
@@ -682,7 +944,8 @@ def exit_ctc_losses(enc_out: Tensor, targets: Tensor, target_len: Tensor, blank:
 
 class _ExitHeadsFn(torch.autograd.Function):
     """All exit heads on given encoder taps: log_softmax(taps[e] . W_e^T + b_e) (early_exit.py:629-631), forward through
-    the HIP head kernel, backward = HIP log-softmax backward + the two plain GEMMs of a Linear's backward."""
+    the HIP head kernel, backward = HIP log-softmax backward + the two GEMMs of a Linear's backward on the training GEMM
+    (eec_train_head_backward)."""
 
     @staticmethod
     def forward(ctx, model, taps, *wb):
@@ -708,16 +971,19 @@ class _ExitHeadsFn(torch.autograd.Function):
         V = out.size(-1)
         dev = taps.device
         g = g.contiguous().float()
-        dlogits = torch.empty_like(out)
+        lib = capi.load()
+        M = B * Tq
+        dW = [torch.empty_like(w) for w in ws]
+        db = [torch.empty((V,), dtype=torch.float32, device=dev) for _ in range(E)]
+        dtaps = torch.empty_like(taps) if ctx.need_taps else None
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream(dev).cuda_stream
-            capi.check(capi.load().eec_logsoftmax_backward(out.data_ptr(), g.data_ptr(), E * B * Tq, V, dlogits.data_ptr(),
-                                                           C.c_void_p(stream)), "eec_logsoftmax_backward")
-        dl = dlogits.reshape(E, B * Tq, V)
-        x = taps.reshape(E, B * Tq, D)
-        dW = [dl[e].t() @ x[e] for e in range(E)]  # plain fp32 library GEMMs (rocBLAS through torch)
-        db = [dl[e].sum(0) for e in range(E)]
-        dtaps = torch.stack([dl[e] @ ws[e] for e in range(E)]).reshape(taps.shape) if ctx.need_taps else None
+            scratch = torch.empty((lib.eec_train_head_backward_scratch_floats(M, V, D),), dtype=torch.float32, device=dev)
+            for e in range(E):  # log-softmax backward + the two GEMMs of a Linear's backward on the training GEMM (bf16x3)
+                _trainer_check(lib.eec_train_head_backward(taps[e].data_ptr(), ws[e].data_ptr(), out[e].data_ptr(), g[e].data_ptr(), M, V, D, 3,
+                                                           dtaps[e].data_ptr() if dtaps is not None else None, dW[e].data_ptr(), db[e].data_ptr(),
+                                                           scratch.data_ptr(), C.c_void_p(stream)), "eec_train_head_backward")
+            scratch.record_stream(torch.cuda.current_stream(dev))
         return (None, dtaps, *dW, *db)
 
 

@@ -300,6 +300,35 @@ typedef void (*eec_group_done_fn)(int group, void* user);
 int eec_train_backward_ex(eec_trainer* tr, const eec_params* params, const eec_params* grads, const float* out, const float* grad_out,
                           const float* grad_taps, void* workspace, size_t workspace_bytes, void* stream, eec_group_done_fn on_group,
                           void* user);
+/* ---- Building blocks of the training step: what `--model_type splitformer / zipformer` need (train.py:180-208) --------------
+ * The same modules as eec_train_forward / _backward, cut where those models put their own glue (strided slices, repeats, adds
+ * between Conformer groups: early_exit.py:117-224, 227-364).  Stateless: the activations a backward needs are recorded in the
+ * caller's `workspace` (256-byte aligned, *_workspace_bytes; untouched until the matching backward, which takes the same
+ * geometry, seed, drop_prob and site numbers).  A GROUP = n_layers ConformerLayers (torchaudio Conformer(num_layers=n_layers))
+ * on rows x [B][T'][D] with key lengths key_len [B] (int32, device): x_out [B][T'][D], bn_batch_stats [n_layers][2][D] as in
+ * eec_train_forward; the backward writes the gradient of every layer parameter (grads mirrors layers) and grad_in = dLoss/dx_in.
+ * site_base numbers the group's dropout sites (7 per layer): calls of one step must use disjoint ranges.  The STEM =
+ * Conv1d(k3, s2) [-> Conv1d(k3, s2) when sub1_* are given] -> + positional encoding -> dropout: x_out [B][To][D], To = T1 or T';
+ * no gradient with respect to mel.  The HEAD = log_softmax(x . W^T + b) and the backward of exactly that. */
+size_t eec_train_group_workspace_bytes(const eec_config* cfg, int n_layers, int B, int Tq);
+int eec_train_group_forward(const eec_config* cfg, const eec_layer_params* layers, int n_layers, const float* x_in, const int32_t* key_len, int B,
+                            int Tq, int passes, float drop_prob, uint64_t seed, uint32_t site_base, float* x_out, float* bn_batch_stats,
+                            void* workspace, size_t workspace_bytes, void* stream);
+int eec_train_group_backward(const eec_config* cfg, const eec_layer_params* layers, const eec_layer_params* grads, int n_layers, const float* x_in,
+                             const int32_t* key_len, int B, int Tq, int passes, float drop_prob, uint64_t seed, uint32_t site_base,
+                             const float* grad_out, float* grad_in, void* workspace, size_t workspace_bytes, void* stream);
+size_t eec_train_stem_workspace_bytes(const eec_config* cfg, int B, int T, int two_convs);
+int eec_train_stem_forward(const eec_config* cfg, const float* sub0_w, const float* sub0_b, const float* sub1_w, const float* sub1_b,
+                           const float* pe, const float* mel, int B, int T, int passes, float drop_prob, uint64_t seed, uint32_t site, float* x_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+int eec_train_stem_backward(const eec_config* cfg, int two_convs, int B, int T, int passes, float drop_prob, uint64_t seed, uint32_t site,
+                            const float* grad_x, float* g_sub0_w, float* g_sub0_b, float* g_sub1_w, float* g_sub1_b, void* workspace,
+                            size_t workspace_bytes, void* stream);
+int eec_train_head_forward(const float* x, const float* W, const float* b, int M, int V, int D, int passes, float* logp, float* scratch /* M*V */,
+                           void* stream);
+size_t eec_train_head_backward_scratch_floats(int M, int V, int D);
+int eec_train_head_backward(const float* x, const float* W, const float* logp, const float* grad_logp, int M, int V, int D, int passes, float* dx,
+                            float* dW, float* db, float* scratch, void* stream);
 /* C = alpha * A . B^T (+ bias) on the training GEMM (test hook): A [M][K], B [N][K], C [M][N] fp32 row-major on the device */
 int eec_train_gemm(const float* A, const float* B, const float* bias, float* C, int M, int N, int K, int passes, int a_transposed,
                    int b_transposed, void* stream);

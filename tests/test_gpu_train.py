@@ -14,7 +14,7 @@ import torch
 
 from conftest import base_kwargs, ref_decoder_logits
 from early_exit_transformer_amd import capi, synth
-from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses, full_conformer
+from early_exit_transformer_amd.model import Early_conformer, Early_zipformer, Splitformer, exit_ctc_losses, full_conformer
 from oracle import conformer_ref as R
 
 pytestmark = pytest.mark.gpu
@@ -138,6 +138,43 @@ def test_deep_training_step_matches_oracle_autograd(cfg, B, T, lens, tol):
     assert abs(loss.item() - want_loss.item()) < 3e-4 * max(1.0, abs(want_loss.item()))
     loss.backward()
     compare_grads(grads_of(gpu), grads_of(ref), tol, f"bf16x3, {kw['n_enc_exits'] * kw['n_enc_layers']} layers")
+
+
+@pytest.mark.parametrize("which,cfg,B,T,lens", [
+    ("splitformer", dict(SMALL, n_enc_exits=3, n_enc_layers=1), 3, 131, [131, 90, 57]),        # T' = 32 (even)
+    ("splitformer", dict(SMALL, n_enc_exits=2, n_enc_layers=2, n_head=2), 2, 151, [151, 100]),  # T' = 37 (odd: the padded branch)
+    ("zipformer", dict(SMALL, n_enc_exits=19, n_enc_layers=1, d_feed_forward=96), 2, 139, [139, 80]),  # T1 = 69: every stack pads
+])
+def test_other_model_types_train_on_the_hip_path(which, cfg, B, T, lens):
+    """train.py:180-208: Splitformer / Early_zipformer in train mode -- stem, every Conformer group (main and down-sampled
+    branches, five frame rates), heads on the HIP training kernels, the glue between them under torch autograd -- against torch
+    autograd on the oracle's restatements of those classes (bit-identical to the reference's, tests/test_oracle.py), dropout 0:
+    log-probs, loss, the gradient of every parameter, BatchNorm running statistics."""
+    kw = base_kwargs(**dict(cfg, drop_prob=0.0))
+    ref = (R.SplitformerRef if which == "splitformer" else R.EarlyZipformerRef)(**kw)
+    sd = synth.synth_state_dict(ref.state_dict(), seed=53, style="trained")
+    ref.load_state_dict(sd)
+    gpu = (Splitformer if which == "splitformer" else Early_zipformer)(**{**kw, "device": "cuda"})
+    gpu.load_state_dict(sd, strict=True)
+    ref, gpu = ref.train(), gpu.cuda().train()
+    mel, lens = synth.synth_mel(B, 80, T, seed=53), torch.tensor(lens)
+    tgt, tl = synth.synth_targets(B, 5, kw["dec_voc_size"], seed=53)
+    want_out = ref(mel, lens)
+    want_loss = R.summed_exit_ctc_loss(want_out, tgt, tl)
+    want_loss.backward()
+    out = gpu(mel.cuda(), lens)
+    assert out.requires_grad and out.shape == want_out.shape
+    scale = max(1.0, want_out.detach().abs().max().item() / 8.0)
+    err = (out.detach().cpu() - want_out.detach()).abs().max().item()
+    print(f"\n[{which} train fwd] max |dlogp| vs the oracle in train mode: {err:.2e} (max|logp| {want_out.abs().max().item():.1f})")
+    assert err < 2e-4 * scale
+    loss = exit_ctc_losses(out, tgt, tl).sum()
+    assert abs(loss.item() - want_loss.item()) < 2e-4 * max(1.0, abs(want_loss.item()))
+    loss.backward()
+    compare_grads(grads_of(gpu), grads_of(ref), 3e-3, f"{which} bf16x3")
+    for (n, b_ref), (_, b_gpu) in zip(ref.named_buffers(), gpu.named_buffers()):
+        if "running_" in n or "num_batches" in n:
+            assert torch.allclose(b_gpu.cpu().float(), b_ref.float(), rtol=1e-4, atol=1e-6), n
 
 
 def test_frozen_encoder_keeps_train_mode_semantics():
