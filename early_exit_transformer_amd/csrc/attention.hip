@@ -28,6 +28,7 @@ struct AttnLds {
   static constexpr int VBYTES = DH * VLD;
   static constexpr int TOTAL = KBYTES + VBYTES;
   static constexpr int TOTAL2 = KBYTES + 2 * VBYTES;  // with the residual plane of V^T
+  static constexpr int TOTAL3 = 2 * KBYTES + 2 * VBYTES;  // ... and of K (exact mode)
 };
 
 EEC_TL_DEFINE(attn)
@@ -54,8 +55,11 @@ extern "C" int eec_tl_read_attn_all(unsigned long long* out) {
 #define EEC_ATTN_OCC 4
 #endif
 constexpr int kAttnWaves = EEC_ATTN_WAVES, kAttnThreads = 64 * kAttnWaves;
-template <int DH, int NP>
-__global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void attn_kernel(AttnArgs a) {
+// X3 (exact mode, precision f16x3): Q and K arrive with fp16 residual planes and the probabilities are split hi / lo in
+// registers, so both products run as three fp16 MFMA products (hi.hi + lo.hi + hi.lo): the attention path then adds ~1e-6 to the
+// log-prob error instead of ~1e-4 (single-fp16 Q, K, P were what kept f16x3 at 1.2e-4).  Needs vt_lo too.
+template <int DH, int NP, bool X3 = false>
+__global__ __launch_bounds__(kAttnThreads, ((DH == 64 || X3) ? 2 : EEC_ATTN_OCC)) void attn_kernel(AttnArgs a) {
   using L = AttnLds<DH>;
   constexpr int KSQ = DH / 16;  // k-steps of the score product
   constexpr int DT = DH / 32;   // 32-row tiles of O^T
@@ -63,6 +67,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   char* lds_k = smem;
   char* lds_v = smem + L::KBYTES;
   char* lds_vlo = lds_v + L::VBYTES;  // only allocated / used when a.vt_lo is given
+  char* lds_klo = lds_vlo + L::VBYTES;  // X3 only
   const bool v2 = a.vt_lo != nullptr;  // uniform
   const int lane = lane_id(), w = wave_id();
   const int r = lane & 31, hh = lane >> 5;
@@ -75,10 +80,14 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   EEC_TL_STAMP(attn, 0);
   EEC_TL_ALL(0);
   h8 qf[KSQ];
+  [[maybe_unused]] h8 qfl[KSQ];
   if (active) {
-    const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + r) * DH + 8 * hh;
+    const size_t qoff = ((size_t)bh * a.Tp + q0 + r) * DH + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) qf[ks] = *(const h8*)(qp + ks * 16);
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[ks] = *(const h8*)(a.q + qoff + ks * 16);
+      if constexpr (X3) qfl[ks] = *(const h8*)(a.q_lo + qoff + ks * 16);
+    }
   }
   f32x16 o[DT];
 #pragma unroll
@@ -90,6 +99,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
   const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
   const half_t* vlbase = v2 ? a.vt_lo + (size_t)bh * DH * a.Tp : vbase;
+  [[maybe_unused]] const half_t* klbase = X3 ? a.k_lo + (size_t)bh * a.Tp * DH : kbase;
   for (int kc0 = 0; kc0 < len; kc0 += kKC) {
     if (kc0) __syncthreads();
     // stage K rows [kc0, kc0+KC) and V^T columns of the same keys; zero beyond Tp.  All global loads of
@@ -100,11 +110,16 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       constexpr int KIT = kKC * KP / kAttnThreads, VIT = DH * VP / kAttnThreads;
       static_assert(kKC * KP % kAttnThreads == 0 && DH * VP % kAttnThreads == 0, "staging loops assume whole passes");
       uint4 kv[KIT], vv[VIT], vl[VIT];
+      [[maybe_unused]] uint4 kl[KIT];
 #pragma unroll
       for (int it = 0; it < KIT; ++it) {
         const int p = it * kAttnThreads + threadIdx.x, row = p / KP, c = p % KP;
         kv[it] = make_uint4(0, 0, 0, 0);
-        if (kc0 + row < a.Tp) kv[it] = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
+        if constexpr (X3) kl[it] = make_uint4(0, 0, 0, 0);
+        if (kc0 + row < a.Tp) {
+          kv[it] = *(const uint4*)(kbase + (size_t)(kc0 + row) * DH + c * 8);
+          if constexpr (X3) kl[it] = *(const uint4*)(klbase + (size_t)(kc0 + row) * DH + c * 8);
+        }
       }
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
@@ -121,6 +136,7 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       for (int it = 0; it < KIT; ++it) {
         const int p = it * kAttnThreads + threadIdx.x, row = p / KP, c = p % KP;
         *(uint4*)(lds_k + row * L::KLD + c * 16) = kv[it];
+        if constexpr (X3) *(uint4*)(lds_klo + row * L::KLD + c * 16) = kl[it];
       }
 #pragma unroll
       for (int it = 0; it < VIT; ++it) {
@@ -147,7 +163,12 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
         if (kt0 + j < nkt) {  // wave-uniform
 #pragma unroll
           for (int ks = 0; ks < KSQ; ++ks) {
-            const h8 kf = *(const h8*)(lds_k + ((kt0 + j) * 32 + r) * L::KLD + (ks * 16 + 8 * hh) * 2);
+            const int koff = ((kt0 + j) * 32 + r) * L::KLD + (ks * 16 + 8 * hh) * 2;
+            const h8 kf = *(const h8*)(lds_k + koff);
+            if constexpr (X3) {  // the two correction products first, the main product last (as the GEMMs of this mode)
+              s[j] = mfma16(*(const h8*)(lds_klo + koff), qf[ks], s[j]);
+              s[j] = mfma16(kf, qfl[ks], s[j]);
+            }
             s[j] = mfma16(kf, qf[ks], s[j]);
           }
         }
@@ -171,13 +192,16 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
       m_run = m_new;
       float psum = 0.f;
       h8 pf[KB][2];
+      [[maybe_unused]] h8 pfl[KB][2];
 #pragma unroll
       for (int j = 0; j < KB; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float p = __builtin_amdgcn_exp2f(s[j][i] - m_new);
           psum += p;
-          pf[j][i >> 3][i & 7] = (half_t)p;
+          const half_t ph = (half_t)p;
+          pf[j][i >> 3][i & 7] = ph;
+          if constexpr (X3) pfl[j][i >> 3][i & 7] = (half_t)(p - (float)ph);
         }
       l_run = l_run * alpha + psum;
 #pragma unroll
@@ -190,8 +214,10 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
               const int voff = (dt * 32 + r) * L::VLD + ((kt0 + j) * 32 + ks * 16 + 8 * hh) * 2;
-              o[dt] = mfma16(*(const h8*)(lds_v + voff), pf[j][ks], o[dt]);
+              const h8 vf = *(const h8*)(lds_v + voff);
               if (v2) o[dt] = mfma16(*(const h8*)(lds_vlo + voff), pf[j][ks], o[dt]);
+              if constexpr (X3) o[dt] = mfma16(vf, pfl[j][ks], o[dt]);
+              o[dt] = mfma16(vf, pf[j][ks], o[dt]);
             }
           }
       }
@@ -222,17 +248,22 @@ __global__ __launch_bounds__(kAttnThreads, (DH == 64 ? 2 : EEC_ATTN_OCC)) void a
   EEC_TL_ALL(1);
 }
 
-template <int DH, int NP>
+template <int DH, int NP, bool X3 = false>
 static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
-  auto k = attn_kernel<DH, NP>;
-  constexpr int lds_max = AttnLds<DH>::TOTAL2;
-  const int lds = a.vt_lo ? AttnLds<DH>::TOTAL2 : AttnLds<DH>::TOTAL;
+  auto k = attn_kernel<DH, NP, X3>;
+  constexpr int lds_max = X3 ? AttnLds<DH>::TOTAL3 : AttnLds<DH>::TOTAL2;
+  const int lds = X3 ? AttnLds<DH>::TOTAL3 : a.vt_lo ? AttnLds<DH>::TOTAL2 : AttnLds<DH>::TOTAL;
   if (hipError_t e = ensure_max_lds((const void*)k, lds_max); e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.Tq + 32 * kAttnWaves - 1) / (32 * kAttnWaves), a.H, a.B), dim3(kAttnThreads), lds, st, a);
   return hipGetLastError();
 }
 
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st) {
+  if (np == 3 && a.q_lo && a.k_lo && a.vt_lo) {  // exact mode
+    if (a.dh == 32) return launch_attn_t<32, 3, true>(a, st);
+    if (a.dh == 64) return launch_attn_t<64, 3, true>(a, st);
+    return hipErrorInvalidValue;
+  }
   if (a.dh == 32) return np == 3 ? launch_attn_t<32, 3>(a, st) : launch_attn_t<32, 1>(a, st);
   if (a.dh == 64) return np == 3 ? launch_attn_t<64, 3>(a, st) : launch_attn_t<64, 1>(a, st);
   return hipErrorInvalidValue;

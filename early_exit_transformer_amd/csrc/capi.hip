@@ -163,8 +163,8 @@ Workspace carve_ws(const eec_config& c, int B, int T, char* base) {
   w.y = a.take<float>((size_t)(c.n_exits > 1 ? c.n_exits - 1 : 0) * M * D);
   w.mid_hi = a.take<half_t>((size_t)B * T1 * D);
   w.mid_lo = a.take<half_t>((size_t)B * T1 * D);
-  w.q = a.take<half_t>((size_t)B * Tp * D);
-  w.k = a.take<half_t>((size_t)B * Tp * D);
+  w.q = a.take<half_t>((size_t)2 * B * Tp * D);   // hi plane, then the residual plane (exact mode f16x3 only)
+  w.k = a.take<half_t>((size_t)2 * B * Tp * D);
   w.vt = a.take<half_t>((size_t)2 * B * Tp * D);  // hi plane, then the residual plane
   w.p_hi = a.take<half_t>(M * D);
   w.p_lo = a.take<half_t>(M * D);
@@ -226,6 +226,7 @@ struct LayerBufs {
   float* x;
   half_t *q, *k, *vt, *vt_lo, *p_hi, *p_lo, *g;
   const int* key_len;
+  half_t *q_lo = nullptr, *k_lo = nullptr;  // exact mode (f16x3): Q and K keep their fp16 residuals, attention runs as its own launch
 };
 struct LayerFormats {
   int ffn, front, qkv, att, glu;  // operand formats of the GEMM groups (1, 3 or 8)
@@ -236,7 +237,9 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
   const eec_config& c = enc->cfg;
   const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
   auto qkv_args = [&](const PackedLayer& L) {
-    return QkvArgs{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo, L.attn_in_f8};
+    QkvArgs q{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo, L.attn_in_f8};
+    q.q_lo = b.q_lo, q.k_lo = b.k_lo;
+    return q;
   };
   auto stage1 = [&](const PackedLayer& L) {
     return FfnStage{L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1p, L.ffn1_b1, L.ffn1_w2p, L.ffn1_b2, nullptr, nullptr,
@@ -253,9 +256,10 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     const PackedLayer& L = enc->layers[li];
     const bool last = li + 1 == l1;
     AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
+    at.q_lo = b.q_lo, at.k_lo = b.k_lo;
     ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
     GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g, L.conv_pw1_f8};
-    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1)) {
+    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1) && !b.q_lo) {
       // two launches per layer: the attention of a row tile runs in the prologue of the out_proj / GLU kernel
       TIMED(KC_PROJ_GLU, launch_attn_proj_glu(at, pr, ga, np.glu, st));
     } else {
@@ -519,6 +523,11 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
   // operand format per GEMM group of the production plan (a diagnostic build can override them one by one)
   int np_qkv = np_p, np_att = np_o, np_glu = np_p, np_front = np_p, np_head = np_o;
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * c.d_model : nullptr;  // V keeps its fp16 residual in the split modes
+  // exact parity mode (f16x3): Q, K and the attention probabilities keep their fp16 residuals as well (three MFMA products per
+  // attention product, attention as its own launch): what remains of the log-prob error is the GLU output's fp16 rounding
+  const bool exact_attn = precision == EEC_PREC_F16X3 && c.arch == EEC_ARCH_CONFORMER;
+  half_t* const q_lo = exact_attn ? ws.q + (size_t)B * Tp * c.d_model : nullptr;
+  half_t* const k_lo = exact_attn ? ws.k + (size_t)B * Tp * c.d_model : nullptr;
 #ifdef EEC_NP_EXPERIMENT
   if (const char* ov = getenv("EEC_NP_OVERRIDE")) {  // e.g. "qkv=1,glu=1": error-budget experiments (tools/np_budget.py)
     auto pick = [&](const char* key, int& dst) {
@@ -593,7 +602,8 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (taps_opt) return taps_opt + (size_t)e * M * D;
       return (out && li + 1 != n_layers) ? ws.y + (size_t)e * M * D : nullptr;
     };
-    const LayerBufs bufs{ws.x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, ws.enc_len};
+    LayerBufs bufs{ws.x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, ws.enc_len};
+    bufs.q_lo = q_lo, bufs.k_lo = k_lo;
     const LayerFormats nps{np_ffn, np_front, np_qkv, np_att, np_glu};
     if (int rc = run_layer_plan(enc, 0, n_layers, bufs, B, Tq, nps, tap_of, st)) return rc;
     if (out) {
@@ -626,8 +636,10 @@ static int forward_impl(eec_encoder* enc, const float* mel, const int64_t* lengt
       if (done()) return finish_dbg();
       {
         QkvArgs a{ws.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, ws.q, ws.k, ws.vt, vt_lo, L.attn_in_f8};
+        a.q_lo = q_lo, a.k_lo = k_lo;
         TIMED(KC_QKV, launch_qkv(a, np_qkv, st));
         AttnArgs at{ws.q, ws.k, ws.vt, ws.enc_len, B, H, Tq, Tp, D / H, ws.p_hi, ws.p_lo, vt_lo};
+        at.q_lo = q_lo, at.k_lo = k_lo;
         TIMED(KC_ATTN, launch_attention(at, np_o, st));
         ProjResArgs pr{ws.x, M, D, ws.p_hi, ws.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
         GluArgs ga{ws.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, ws.g, L.conv_pw1_f8};
@@ -698,8 +710,8 @@ static GroupWs carve_group_ws(const eec_config& c, int B, int Tq, char* base) {
   Arena a;
   a.base = base;
   GroupWs w;
-  w.q = a.take<half_t>((size_t)B * Tp * D);
-  w.k = a.take<half_t>((size_t)B * Tp * D);
+  w.q = a.take<half_t>((size_t)2 * B * Tp * D);   // hi plane, then the residual plane (exact mode f16x3 only)
+  w.k = a.take<half_t>((size_t)2 * B * Tp * D);
   w.vt = a.take<half_t>((size_t)2 * B * Tp * D);  // hi plane, then the residual plane
   w.p_hi = a.take<half_t>(M * D);
   w.p_lo = a.take<half_t>(M * D);
@@ -732,7 +744,8 @@ int eec_encoder_group_forward(eec_encoder* enc, int group, float* x, const int32
   const int Tp = (Tq + 31) / 32 * 32, D = c.d_model;
   half_t* const vt_lo = np_o == 3 ? ws.vt + (size_t)B * Tp * D : nullptr;
   if (Tp != Tq) EEC_HIP(hipMemsetAsync(ws.vt, 0, (size_t)2 * B * Tp * D * sizeof(half_t), st));
-  const LayerBufs bufs{x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, key_len};
+  LayerBufs bufs{x, ws.q, ws.k, ws.vt, vt_lo, ws.p_hi, ws.p_lo, ws.g, key_len};
+  if (precision == EEC_PREC_F16X3) bufs.q_lo = ws.q + (size_t)B * Tp * D, bufs.k_lo = ws.k + (size_t)B * Tp * D;  // exact mode (forward_impl)
   const int np_p = (precision == EEC_PREC_F16F8 && c.d_model == 256 && c.d_ff % 128 == 0) ? 8 : np_o;
   const LayerFormats nps{np_ffn, np_p, np_p, np_o, np_p};  // {ffn, front, qkv, att, glu}
   const int l0 = group * c.layers_per_exit;

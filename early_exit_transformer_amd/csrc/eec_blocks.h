@@ -133,13 +133,19 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
       if (ok[mt]) {
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-          half_t* dst = a.q + ((size_t)(rb[mt] * a.H + hd[j]) * a.Tp + rt[mt]) * dh + d0[j];
+          const size_t qoff = ((size_t)(rb[mt] * a.H + hd[j]) * a.Tp + rt[mt]) * dh + d0[j];
+          half_t* dst = a.q + qoff;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            h4 o;
+            h4 o, ol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = to_half_sat(acc[mt][j][4 * g + i] * scale);
+            for (int i = 0; i < 4; ++i) {
+              const float v = acc[mt][j][4 * g + i] * scale;
+              o[i] = to_half_sat(v);
+              ol[i] = (half_t)(v - (float)o[i]);
+            }
             *(h4*)(dst + 8 * g) = o;
+            if (a.q_lo) *(h4*)(a.q_lo + qoff + 8 * g) = ol;
           }
         }
       }
@@ -152,13 +158,19 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
     if (ok[mt]) {
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        half_t* dst = a.k + ((size_t)(rb[mt] * a.H + hd[j]) * a.Tp + rt[mt]) * dh + d0[j];
+        const size_t koff = ((size_t)(rb[mt] * a.H + hd[j]) * a.Tp + rt[mt]) * dh + d0[j];
+        half_t* dst = a.k + koff;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          h4 o;
+          h4 o, ol;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = to_half_sat(acc[mt][j][4 * g + i]);
+          for (int i = 0; i < 4; ++i) {
+            const float v = acc[mt][j][4 * g + i];
+            o[i] = to_half_sat(v);
+            ol[i] = (half_t)(v - (float)o[i]);
+          }
           *(h4*)(dst + 8 * g) = o;
+          if (a.k_lo) *(h4*)(a.k_lo + koff + 8 * g) = ol;
         }
       }
     }

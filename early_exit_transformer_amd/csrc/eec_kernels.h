@@ -38,6 +38,7 @@ struct QkvArgs {
   half_t *q, *k, *vt;  // q,k: [B][H][Tp][dh]; vt: [B][H][dh][Tp] (key order permuted per 16)
   half_t* vt_lo = nullptr;  // optional: fp16 residual V - fp16(V), same layout (the PV product then runs on hi + lo)
   const uint4* wf8 = nullptr;  // the same matrix as the f8 record stream (NP == 8)
+  half_t *q_lo = nullptr, *k_lo = nullptr;  // optional (exact mode): fp16 residuals of the scaled Q and of K, same layouts
 };
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
@@ -98,6 +99,8 @@ struct AttnArgs {
   int B, H, Tq, Tp, dh;
   half_t *o_hi, *o_lo;  // [M][256]
   const half_t* vt_lo = nullptr;  // optional residual plane of V^T (see QkvArgs)
+  const half_t *q_lo = nullptr, *k_lo = nullptr;  // optional residual planes of Q and K: the score and PV products then run as three
+                                                  // fp16 MFMA products each (the probabilities are split hi / lo in registers)
 };
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st);
 

@@ -274,9 +274,13 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   len = min(len_raw, a.Tq);
   nkt = (len + 31) / 32;
 #endif
-#ifdef EEC_ATTN_PRIO  // A/B knob: static priority for the younger half of the workgroup (waves 4-7 lose every issue arbitration)
-  if (w >= 4) __builtin_amdgcn_s_setprio(EEC_ATTN_PRIO);
+  // static priority for the younger half of the workgroup: waves 4-7 lose every issue arbitration against their SIMD partners
+  // (wave 7 reached its first key block 4.4 k cycles after wave 0 and stayed behind: the tile's barrier waited 6.8 k cycles for it;
+  // profiles/r03_proj_glu_timeline.txt).  One setprio, no per-phase flips; A/B 37.7 -> 36.6 us per launch.
+#ifndef EEC_ATTN_PRIO
+#define EEC_ATTN_PRIO 1
 #endif
+  if (EEC_ATTN_PRIO > 0 && w >= 4) __builtin_amdgcn_s_setprio(EEC_ATTN_PRIO);
   EEC_TL_STAMP(glu, 11);
   for (int kt0 = 0; kt0 < nkt; kt0 += 2 * KB) {
     if (kt0 + KB < nkt) fetch(fb, kt0 + KB, nkt - 1);
@@ -288,9 +292,7 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
     }
     EEC_TL_STAMP(glu, kt0 == 0 ? 13 : 15);
   }
-#ifdef EEC_ATTN_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
+  if (EEC_ATTN_PRIO > 0) __builtin_amdgcn_s_setprio(0);
   // normalise and write the planes.  No valid key at all (length 0): the installed torch returns zeros ("safe softmax").
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {

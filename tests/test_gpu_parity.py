@@ -2,8 +2,8 @@
 nn.Module -> ctypes -> C-ABI, against the CPU oracle and the committed golden fixtures.
 
 Tolerances (max |delta log-prob| vs the fp32 reference path, stated per operand mode):
-    f16f8  1e-3   (default: as f16x3 with the feed-forward corrections in block-scaled fp8; measured 3.9e-4)
-    f16x3  1e-3   (north_star's tolerance; measured 1.2-1.4e-4 on the 12-layer model)
+    f16f8  1e-3   (default: as f16x3 with the correction products of every GEMM but the heads in block-scaled fp8; measured 4.1e-4)
+    f16x3  1e-3   (north_star's tolerance, FLAT on every fixture incl. the peaky one; measured 3.8e-5 on the 12-layer model, 3.7e-4 peaky)
     mixed  2.5e-3 (measured 1.0-1.3e-3)
     f16    6e-3   (measured 3.0e-3)
 """
@@ -80,8 +80,11 @@ def test_golden_logprobs(name, prec):
           f"err/scale {err / scale:.2e}  tolerance {logp_tolerance(prec, z['logp']):.2e}")
     assert err_top <= err
     assert err < logp_tolerance(prec, z["logp"]), f"{name}/{prec}: max|dlogp| {err:.3e} at max|logp| {scale:.1f}"
-    if name != "config1_peaky":  # the flat north-star tolerance holds outright on every near-uniform fixture
-        assert err < TOL[prec]
+    # the flat north-star tolerance (1e-3, no scaling) holds outright on every near-uniform fixture in every mode's own flat bound,
+    # and in the exact parity mode f16x3 ALSO on the peaky (heads x 8, trained-like) fixture: Q, K and the attention probabilities
+    # keep fp16 residuals there (round 3; measured 3.7e-4 at max|logp| 59)
+    if name != "config1_peaky" or prec == "f16x3":
+        assert err < TOL[prec], f"{name}/{prec}: the FLAT tolerance: max|dlogp| {err:.3e}"
     # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only).  A logit error on a row's
     # dominant class shifts the whole row's log-probs together, so the errors of a row do not average out: the bound is
     # a quarter of "every element off by the tolerance"

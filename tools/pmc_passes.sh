@@ -16,4 +16,4 @@ for grp in \
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-include-regex "$REGEX" --output-format csv -d "$OUT/pass$i" -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-modes "$@" > "$OUT/pass$i.log" 2>&1 || echo "pass $i failed"
 done
-python3 tools/pmc_summary.py "$OUT"
+python3 tools/pmc_summary.py "$OUT" ${PMC_GRID:-131072}   # the headline shape only: 256 workgroups x 512 threads
