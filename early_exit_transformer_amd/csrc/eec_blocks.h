@@ -81,7 +81,8 @@ __device__ __forceinline__ void proj_gemm(f32x16 (&acc)[MT][NT], const char* sme
   if constexpr (NP == 8) {
     const char* a8_lane = smem + G::kAPlane + (lane & 31) * G::kA8Ld + hh * 32;
     const uint4* rec = w.wf8 + (size_t)t0 * NG * kF8Rec + lane;
-    gemm_ring_f8<NG, NT, true, PF, NoSide, 0, kProjNWB, 0, MT>(acc, a_lane, G::kALd, a8_lane, G::kA8Ld, rec, (size_t)NG * kF8Rec, st.r, st.wg);
+    gemm_ring_f8<NG, NT, true, PF, NoSide, 0, kProjNWB, 0, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(acc, a_lane, G::kALd, a8_lane, G::kA8Ld, rec,
+                                                                                                    (size_t)NG * kF8Rec, st.r, st.wg);
   } else {
     gemm_ring<NP, KS, NT, true, PF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(w.wp, t0), (size_t)KS * 128, st.r);
   }
@@ -372,6 +373,10 @@ __device__ __forceinline__ void dw_front(char* smem, const DwArgs& d, int M, int
       if (NP == 8) {  // e5m2 bytes of the two residuals (adjacent channels are adjacent in the permuted byte plane)
         const unsigned lb = __builtin_bit_cast(unsigned, lo8_gain(sp.lo));
         *(unsigned short*)(smem + G::kAPlane + rl * G::kA8Ld + lo8_pos(c)) = (unsigned short)(((lb >> 8) & 0xffu) | ((lb >> 16) & 0xff00u));
+        if (EEC_X_HI8) {
+          const unsigned hb = __builtin_bit_cast(unsigned, sp.hi);
+          *(unsigned short*)(smem + G::kAPlane + rl * G::kA8Ld + G::kA8Hi + lo8_pos(c)) = (unsigned short)(((hb >> 8) & 0xffu) | ((hb >> 16) & 0xff00u));
+        }
       }
     }
   }

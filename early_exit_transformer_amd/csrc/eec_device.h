@@ -48,6 +48,14 @@ constexpr float kHalfMax = 65504.0f;
 // 32-row tiles (acc[2][1]); D = 512: 32-row tiles, a wave owns TWO adjacent column tiles and one row tile (acc[1][2]).
 // LDS geometry in bytes; row pads of one 16-B slot make ds_read_b128 of "32 different rows, same column"
 // conflict-free (stride = 4 banks mod 64).
+// EEC_X_HI8 (experiment knob, off): the activations' e5m2 hi bytes (the a_hi8 operand of the weight-residual correction product)
+// are written ONCE by whoever writes the planes and read as MFMA operands straight from LDS, instead of being re-made with two
+// v_perm per fragment and k-step by every wave that multiplies the tile (chain kernel producers: -64 VALU per slot and wave).
+// Bit-identical results; same-box A/B: 171.6 us with, 171.0 us without (profiles/r03_ab_chain_knobs.txt) -- the producers' VALU
+// issue is not what bounds the slot.
+#ifndef EEC_X_HI8
+#define EEC_X_HI8 0
+#endif
 template <int D>
 struct Geo {
   static_assert(D == 256 || D == 512, "d_model must be 256 or 512");
@@ -59,7 +67,11 @@ struct Geo {
   static constexpr int kRPW = kRows / 8;        // rows per wave in a row pass: 8 / 4
   static constexpr int kALd = (D + 8) * 2;      // 528 / 1040 : [rows][D] fp16 activation plane
   static constexpr int kAPlane = kRows * kALd;  // 33792 / 33280
-  static constexpr int kA8Ld = D + 16;          // 272 / 528  : [rows][D] e5m2 byte plane (NP == 8)
+  // NP == 8 byte plane, per row: [D e5m2 residual bytes][D e5m2 top bytes of the hi halves (EEC_X_HI8)][16 pad], both in the
+  // permuted MX slot order (lo8_pos).  With the hi bytes the row stride equals the fp16 plane's (conflict-free ds_read_b128) and the
+  // plane fills exactly the region the fp16 lo plane of the split format has: no extra LDS.
+  static constexpr int kA8Ld = EEC_X_HI8 ? 2 * D + 16 : D + 16;  // 528 / 1040 (272 / 528 without the hi bytes)
+  static constexpr int kA8Hi = D;               // byte offset of the hi8 half inside a row
   static constexpr int kELd = (D + 4) * 4;      // 1040 / 2064: [rows][D] fp32 exchange tile
   static constexpr int kETile = kRows * kELd;   // 66560 / 66048
 };
@@ -448,7 +460,10 @@ __device__ __forceinline__ void f8_group_load(WGroupF8<NT>& g, const uint4* __re
 // CONT: the stream CONTINUES into another product of the same shape whose first record (+lane) is `next_lane` (wave-uniform,
 // may be null): the last PF k-steps refill the ring -- and the last NW groups their lo8 buffers -- with that product's first
 // steps / groups, so the caller starts it with a full pipeline and no separate fill.
-template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0, int MT = 2, bool CONT = false>
+// A8HI > 0: the activation tile's byte plane also holds the hi bytes, A8HI bytes behind the residual bytes of the same row
+// (Geo::kA8Hi; EEC_X_HI8): they are read as the group's operand instead of being permuted out of the fp16 fragments.
+template <int NG, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int NW = NG, int DROP = 0, int MT = 2, bool CONT = false,
+          int A8HI = 0>
 __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, const char* a8_lane,
                                              int ld8_bytes, const uint4* __restrict__ rec_lane, size_t nt_stride,
                                              WRing<1, PF, NT>& r, WGroupF8<NT> (&wg)[NW], Side side = Side(),
@@ -459,7 +474,8 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
   h8 ah[2][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) ah[0][mt] = *(const h8*)(a_lane + mt * 32 * ld_bytes);
-  uint2 a8[MT][4];  // [mt][step in group]: e5m2 of the activation hi fragments
+  [[maybe_unused]] uint2 a8[MT][4];  // [mt][step in group]: e5m2 of the activation hi fragments (A8HI == 0)
+  [[maybe_unused]] i32x8 ahi8[MT];   // ... or the group's hi bytes read from the byte plane (A8HI > 0)
   uint2 w8[NT][4];  // [nt][step in group]: e5m2 of the weight hi fragments
   i32x8 alo[MT];    // activation lo8 of the current group
 #pragma unroll
@@ -483,11 +499,18 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
         const uint4 l0 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64);
         const uint4 l1 = *(const uint4*)(a8_lane + mt * 32 * ld8_bytes + g * 64 + 16);
         alo[mt] = (i32x8){(int)l0.x, (int)l0.y, (int)l0.z, (int)l0.w, (int)l1.x, (int)l1.y, (int)l1.z, (int)l1.w};
+        if constexpr (A8HI > 0) {
+          const uint4 h0 = *(const uint4*)(a8_lane + A8HI + mt * 32 * ld8_bytes + g * 64);
+          const uint4 h1 = *(const uint4*)(a8_lane + A8HI + mt * 32 * ld8_bytes + g * 64 + 16);
+          ahi8[mt] = (i32x8){(int)h0.x, (int)h0.y, (int)h0.z, (int)h0.w, (int)h1.x, (int)h1.y, (int)h1.z, (int)h1.w};
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (A8HI == 0) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a8[mt][q] = top_bytes(__builtin_bit_cast(uint4, ah[cur][mt]));
+      for (int mt = 0; mt < MT; ++mt) a8[mt][q] = top_bytes(__builtin_bit_cast(uint4, ah[cur][mt]));
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const uint4 wq = r.q[s % PF][nt][0];
@@ -520,7 +543,9 @@ __device__ __forceinline__ void gemm_ring_f8(f32x16 (&acc)[MT][NT], const char* 
                            (int)G.lo[nt][1].x, (int)G.lo[nt][1].y, (int)G.lo[nt][1].z, (int)G.lo[nt][1].w};
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          const i32x8 ahi = {(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
+          i32x8 ahi;
+          if constexpr (A8HI > 0) ahi = ahi8[mt];
+          else ahi = (i32x8){(int)a8[mt][0].x, (int)a8[mt][0].y, (int)a8[mt][1].x, (int)a8[mt][1].y,
                              (int)a8[mt][2].x, (int)a8[mt][2].y, (int)a8[mt][3].x, (int)a8[mt][3].y};
           // DROP (diagnostic builds only): bit 0 skips the activation-residual term, bit 1 the weight-residual term
           if (SWAP) {
@@ -696,6 +721,10 @@ __device__ __forceinline__ void rows_to_planes(char* lds_act, RowV<Geo<D>::kQ> (
         lg.xy = lo8_gain(s0.lo), lg.zw = lo8_gain(s1.lo);
         const uint2 lb = __builtin_bit_cast(uint2, lg);
         *(unsigned*)(lds_act + G::kAPlane + rl * G::kA8Ld + lo8_pos(col)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+        if (EEC_X_HI8) {
+          const uint2 hb = __builtin_bit_cast(uint2, hi);
+          *(unsigned*)(lds_act + G::kAPlane + rl * G::kA8Ld + G::kA8Hi + lo8_pos(col)) = __builtin_amdgcn_perm(hb.y, hb.x, 0x07050301u);
+        }
       }
     }
   }

@@ -463,13 +463,15 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
               if (st % kSideEvery == 0) silu_pair(prev, hb_prev, st / kSideEvery, khi, klo);
             };
             if constexpr (NP == 8)
-              gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
+              gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(
+                  cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
               gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7), MT>(cur, a_lane, kALd, kAPlane, w1_lane,
                                                                                       0, r1, side);
           } else {
             if constexpr (NP == 8)
-              gemm_ring_f8<D / 64, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1, MT>(cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1);
+              gemm_ring_f8<D / 64, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(cur, a_lane, kALd, a8_lane, kA8Ld,
+                                                                                                                    w1f8_lane(W, ft), 0, r1, wg1);
             else
               gemm_ring<RNP, KS, 1, true, kPF1, NoSide, 0, MT>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
           }

@@ -85,6 +85,7 @@ __device__ __forceinline__ void planes_commit512(char* lds_act, const PlaneRegs<
       typedef _Float16 h8v __attribute__((ext_vector_type(8)));
       const h8v lg = __builtin_bit_cast(h8v, pr.l[it]) * (half_t)kF8ALoGain;  // gain-compensated (eec_device.h, kF8ALoGain)
       *(uint2*)(lds_act + G::kAPlane + rl * G::kA8Ld + lo8_pos(c16 * 8)) = top_bytes(__builtin_bit_cast(uint4, lg));
+      if (EEC_X_HI8) *(uint2*)(lds_act + G::kAPlane + rl * G::kA8Ld + G::kA8Hi + lo8_pos(c16 * 8)) = top_bytes(pr.h[it]);
     }
   }
 }
@@ -315,6 +316,10 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
           lg.xy = lo8_gain(s0.lo), lg.zw = lo8_gain(s1.lo);
           const uint2 lb = __builtin_bit_cast(uint2, lg);
           *(unsigned*)(smem + G::kAPlane + rl * G::kA8Ld + lo8_pos(col)) = __builtin_amdgcn_perm(lb.y, lb.x, 0x07050301u);
+          if (EEC_X_HI8) {
+            const uint2 hb = __builtin_bit_cast(uint2, hi);
+            *(unsigned*)(smem + G::kAPlane + rl * G::kA8Ld + G::kA8Hi + lo8_pos(col)) = __builtin_amdgcn_perm(hb.y, hb.x, 0x07050301u);
+          }
         }
       }
   }
