@@ -228,6 +228,65 @@ def test_data_parallel_buckets_hold_the_same_gradients():
         assert torch.allclose(p.grad, 2 * plain[n], rtol=1e-5, atol=1e-7), n
 
 
+def _dp_train_rank(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # both ranks share the one GPU of this box: gloo, not RCCL
+    try:
+        kw = base_kwargs(**SMALL)
+        _, gpu = make_train_pair(kw, seed=59)
+        B, T = 5, 131  # uneven shards: 3 + 2
+        mel, lens = synth.synth_mel(B, 80, T, seed=59), torch.tensor([131, 90, 57, 131, 100])
+        tgt, tl = synth.synth_targets(B, 9, kw["dec_voc_size"], seed=59)
+        lo, hi = (0, 3) if rank == 0 else (3, 5)
+
+        def local_step():
+            gpu.zero_grad(set_to_none=True)
+            for m in gpu.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            exit_ctc_losses(gpu(mel[lo:hi].cuda(), lens[lo:hi]), tgt[lo:hi], tl[lo:hi]).sum().backward()
+
+        local_step()  # plain local gradients first
+        mine = {n: p.grad.clone() for n, p in gpu.named_parameters()}
+        gpu.enable_data_parallel(hi - lo, min_bucket_bytes=0)
+        local_step()  # ... then the same step with the buckets: reduced group by group from the backward's callback
+        n_coll = gpu.sync_gradients()
+        torch.cuda.synchronize()
+        # what the reduction must give: sum_r (B_r / B) * grad_r, checked on every parameter through an exchange of the local ones
+        worst = 0.0
+        for n, p in gpu.named_parameters():
+            parts = [torch.empty_like(mine[n]).cpu() for _ in range(world)]
+            dist.all_gather(parts, mine[n].cpu())
+            want = sum(parts[r] * ((3, 2)[r] / 5.0) for r in range(world))
+            worst = max(worst, ((p.grad.cpu() - want).abs().max() / (want.abs().max() + 1e-12)).item())
+        in_views = all(p.grad.data_ptr() == gpu._dp["buckets"].view(n, p).data_ptr() for n, p in gpu.named_parameters())
+        if rank == 0:
+            q.put((n_coll, worst, in_views))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_data_parallel_training_step_on_the_product_path():
+    """BASELINE configs[3]'s mechanism with two ranks on this box's one GPU (gloo): the product module in train mode, uneven
+    utterance shards, enable_data_parallel -> each exit group's flat bucket is all-reduced from eec_train_backward_ex's callback
+    while the backward goes on -> sync_gradients.  Every parameter's gradient equals the shard-weighted sum of the ranks' local
+    gradients (BatchNorm statistics stay per replica, as documented), and still lives in its bucket view."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_train_rank, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    n_coll, worst, in_views = q.get(timeout=300)
+    [p.join(120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert n_coll == 3 and in_views  # exit group 1, exit group 0, stem
+    assert worst < 1e-5, worst
+
+
 @pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2)], ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention"])
 def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     """drop_prob > 0: streams cannot match torch's, so the check is internal -- the same seed reproduces the step, another
