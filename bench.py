@@ -610,15 +610,55 @@ def main():
         guard.start_watchdog(float(os.environ.get("EEC_BENCH_TRAIN_TIMEOUT", "240")))
         n_tr = max(3, args.steps // 10)
         lab4 = (f"CTC training step, default 12-layer d_model=256, batch {B}/GPU x {world} GPU(s), mel [80 x {T}] "
-                "(BASELINE.json configs[3]; gradients all-reduced in 64 MB buckets when N > 1)")
+                "(BASELINE.json configs[3]; at N > 1 the per-exit-group gradient buckets are all-reduced under the backward)")
         t_x3 = train_bench(CFG, 3, n_tr, lab4)
         t_bf = train_bench(CFG, 1, n_tr, lab4)
         t3 = None
         if world == 1:
             t3 = train_bench(dict(CFG, d_model=512, n_enc_layers=3), 1, max(2, n_tr // 2),
                              f"CTC training step, 18-layer d_model=512 (6 exits x 3), batch {B}, mel [80 x {T}] (BASELINE.json configs[2])")
+        # AED training step (train.py:36-52, --decoder_mode aed; secondary line, N = 1): full_conformer = the same encoder + six
+        # attention decoders of six layers; forward in train mode, summed exit CTC + cross-entropy losses, backward, clip, AdamW --
+        # encoder AND decoders on the HIP training kernels (eec_train_*, eec_decoder_train_*)
+        t_aed = None
+        if world == 1:
+            try:
+                from early_exit_transformer_amd.model import full_conformer
+                fc = full_conformer(trg_pad_idx=126, n_dec_layers=6, device=dev, **{k: v for k, v in CFG.items() if k != "src_pad_idx"})
+                fc.load_state_dict(synth.synth_state_dict(fc.state_dict(), seed=4, style="init"))
+                fc = fc.to(dev).train()
+                fparams = list(fc.parameters())
+                fopt = torch.optim.AdamW(fparams, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+                ce = torch.nn.CrossEntropyLoss(ignore_index=126)
+                trg_in, trg_out = tgt[:, :-1].contiguous(), tgt[:, 1:].contiguous()
+
+                def aed_step():
+                    fopt.zero_grad(set_to_none=True)
+                    dec, enc = fc(mel, lengths, trg_in)
+                    loss = exit_ctc_losses(enc, tgt, tgt_len).sum() + sum(ce(d.reshape(-1, d.size(-1)), trg_out.reshape(-1)) for d in dec)
+                    loss.backward()
+                    torch.nn.utils.clip_grad_norm_(fparams, 1.0)
+                    fopt.step()
+                    return loss
+                for _ in range(2):
+                    loss = aed_step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                n_aed = max(2, n_tr // 2)
+                for _ in range(n_aed):
+                    loss = aed_step()
+                torch.cuda.synchronize()
+                d = (time.perf_counter() - t1) / n_aed
+                t_aed = {"workload": f"AED training step: full_conformer (12-layer encoder + 6 decoders x 6 layers), batch {B}, mel [80 x {T}], "
+                                     f"{trg_in.size(1)} target tokens; CTC + CE losses, backward, clip, AdamW; encoder and decoders on the HIP training kernels",
+                         "ms_per_step": round(d * 1e3, 3), "value": round(B * T / d, 1), "unit": "mel-frames/s", "steps": n_aed,
+                         "finite_loss": bool(torch.isfinite(loss).item())}
+                del fc, fopt, fparams
+                torch.cuda.empty_cache()
+            except Exception as e:  # a secondary line never takes the record down
+                t_aed = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
-            train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3}
+            train = {"config4_bf16x3": t_x3, "config4_bf16": t_bf, "config3_bf16": t3, "aed_bf16x3": t_aed}
 
         guard.finish()
         emit(train if rank == 0 else None)
