@@ -110,6 +110,10 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP library is not built. Run `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or early_exit_transformer_amd.build.build_library()). There is no CPU fallback.")
+    # torch first: its bundled libamdhip64.so carries the soname libeec.so asks for (libamdhip64.so.7), so the loader
+    # reuses it.  Loaded the other way round, /opt/rocm's copy comes in as well and one process holds two HIP runtimes
+    # (the second to initialise then reports "no ROCm-capable device").
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.eec_last_error.restype = C.c_char_p
     lib.eec_abi_version.restype = C.c_int

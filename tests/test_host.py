@@ -34,6 +34,19 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.eec_abi_version() == 16
 
 
+def test_loading_the_library_first_keeps_one_hip_runtime_in_the_process(lib):
+    """build() then smoke() in one interpreter: dlopen of libeec.so before torch must not bring /opt/rocm's libamdhip64 in
+    beside torch's bundled one (two runtimes in a process: the second reports no device)."""
+    import subprocess
+    import sys
+    code = ("from early_exit_transformer_amd import capi; capi.load(); import torch\n"
+            "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+            "print(len(libs), libs)")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
+
+
 def test_trainer_workspace_sizing_runs_without_a_device(lib):
     """eec_trainer_workspace_bytes is host arithmetic (a dry run of the forward + backward carve): monotonic in the batch and
     of the size the saved activations predict (default model, B = 64, T = 1027: ~10 GB of fp32 tape + scratch)."""
