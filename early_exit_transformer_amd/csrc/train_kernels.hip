@@ -213,7 +213,30 @@ enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3, EPI_RESID = 4, E
 
 // STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
 // contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
-template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES>
+#ifndef EECT_EPI_DIRECT
+#define EECT_EPI_DIRECT 0  // 1: 4-byte stores straight from the accumulators (measured: epilogue 23.5 k cycles against 13.6 k through the slabs)
+#endif
+#ifdef EECT_TL
+// Diagnostic build only (tools/train_gemm_timeline.py): s_memtime stamps of thread 0 of the first 64 workgroups of a launch.
+__device__ unsigned long long eect_tl_buf[64 * 16];
+extern "C" int eect_debug_tl(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(eect_tl_buf), sizeof(eect_tl_buf));
+}
+#define EECT_STAMP(i)                                                                                        \
+  do {                                                                                                       \
+    const unsigned l_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                      \
+    if (threadIdx.x == 0 && l_ < 512 && (l_ & 7) == 0) eect_tl_buf[(l_ >> 3) * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define EECT_STAMP(i)
+#endif
+
+// FANCY: the epilogues with per-element arithmetic (SiLU / SiLU' / dropout / residual) are compiled in.  The plain form (bias,
+// alpha, accumulate, ReLU) is its own instantiation: with every variant in one body a slab's epilogue is 5.6 k instructions
+// (134 KB of code per tile against a 64 KB instruction cache shared by two CUs), and a plain K = 256 GEMM spent 30 k of its
+// workgroup's 65 k cycles there (tools/train_gemm_timeline.py).
+template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES, bool FANCY>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -226,6 +249,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   bf16* a_lo = NP == 3 ? b_hi + EB : a_hi;
   bf16* b_lo = NP == 3 ? a_lo + EA : b_hi;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w / WGN, wn = w % WGN;
+  EECT_STAMP(0);
   // XCD-aware tile map.  Workgroups are dealt round-robin over the 8 XCDs in dispatch order (x fastest, then y, z), each XCD with
   // its own L2: taken naively, the column blocks of one row tile -- which all read the same A rows -- land on eight different
   // L2s and every one of them fetches those rows (measured on the default model: 98 GB of L2-miss reads per training step).
@@ -293,6 +317,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
     store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
     store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
     __syncthreads();
+#ifdef EECT_TL
+    if (kt < 4) EECT_STAMP(4 + 2 * kt);
+#endif
     if (kt + STAGES < nk) load_ab(ra, rb, k_of(kt + STAGES), fast_tag);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -318,6 +345,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
         }
     }
+#ifdef EECT_TL
+    if (kt < 4) EECT_STAMP(5 + 2 * kt);
+#endif
     __syncthreads();
   };
   auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
@@ -332,8 +362,10 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
       }
     }
   };
+  EECT_STAMP(1);
   if (fast) k_loop(FastTag<true>{});
   else k_loop(FastTag<false>{});
+  EECT_STAMP(2);
   if constexpr (!AKC) {
     if (do_rs) {  // uniform over the workgroup.  The k-loop ended with a barrier: LDS is free.
       constexpr int TPG = 256 / (BM / 4);  // threads that hold partial sums of the same four rows
@@ -354,16 +386,59 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // epilogue: the output tile leaves through LDS in slabs of 32 rows, so that every thread stores 16 contiguous bytes of a row
   // (an accumulator lane holds single columns: direct stores are 4-byte stores, four times as many instructions) and the
   // epilogue arithmetic runs on float4s.  The k-loop ended with a barrier: the planes are dead.
-  const DropState ds(g.drop);
+  const int epi = FANCY ? g.epi : (g.epi == EPI_RELU ? EPI_RELU : EPI_NONE);
+  const DropState ds(FANCY ? g.drop : Drop{0.0f, 0, 0});
   const float* __restrict__ aux = g.aux;
   float* __restrict__ C2 = g.C2;
+#if EECT_EPI_DIRECT
+  // straight from the accumulators: for a fixed register index the 64 lanes of a wave hold two rows x 32 consecutive columns,
+  // i.e. every store (and every load of old C / aux) instruction covers two full 128-byte segments -- no LDS round trip and no
+  // barrier (the slab form below spent 13.6 k of a K = 256 workgroup's 47 k cycles on its 8 barriers)
+  {
+    const bool want_pre = g.accumulate || epi == EPI_DSILU || epi == EPI_RESID || epi == EPI_DRELU;
+    const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (wn * TN + nt) * 32 + (lane & 31), mb = m0 + (wm * TM + mt) * 32;
+        const bool nok = n < g.N;
+        const float bv = (g.bias && nok) ? g.bias[n] : 0.0f;
+        float pre[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = mb + acc_row(i, lane);
+          pre[i] = (want_pre && nok && m < g.M) ? pre_src[(long)m * g.c_m + n] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int m = mb + acc_row(i, lane);
+          if (nok && m < g.M) {
+            const long ci = (long)m * g.c_m + n;
+            float t = g.alpha * acc[mt][nt][i] + bv;
+            if (g.accumulate) t += pre[i];
+            if (epi == EPI_DSILU) {
+              const float x = pre[i], sg = sigmoidf_(x);
+              t *= ds.mul((uint64_t)ci) * sg * (1.0f + x * (1.0f - sg));
+            }
+            if (epi == EPI_RELU) t = fmaxf(t, 0.0f);
+            if (epi == EPI_DRELU) t *= pre[i] > 0.0f ? ds.mul((uint64_t)ci) : 0.0f;
+            if (epi == EPI_RESID) t = pre[i] + g.res_scale * t * ds.mul((uint64_t)ci);
+            C[ci] = t;
+            if (epi == EPI_SILU) C2[ci] = t * sigmoidf_(t) * ds.mul((uint64_t)ci);
+            if (epi == EPI_RELU_DROP) C2[ci] = fmaxf(t, 0.0f) * ds.mul((uint64_t)ci);
+          }
+        }
+      }
+  }
+#else
   float* slab = (float*)smem;
   const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
   // what a slab's elements need from memory -- old C (accumulate) or aux (EPI_DSILU), never both -- is requested one slab
   // ahead: the loads of slab s + 1 are in flight while slab s goes through LDS and out
   constexpr int NPS = 32 * (BN / 4) / 256;
   f32x4 pre[BM / 32][NPS];
-  const bool want_pre = cvec && (g.accumulate || g.epi == EPI_DSILU || g.epi == EPI_RESID || g.epi == EPI_DRELU);
+  const bool want_pre = cvec && (g.accumulate || epi == EPI_DSILU || epi == EPI_RESID || epi == EPI_DRELU);
   const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
   auto request = [&](auto sl_tag) __attribute__((always_inline)) {
     constexpr int sl = decltype(sl_tag)::value;
@@ -399,32 +474,32 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
         if (cvec) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] += g.accumulate ? pre[sl][ps][j] : 0.0f;
-          if (g.epi == EPI_DSILU) {
+          if (epi == EPI_DSILU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const float x = pre[sl][ps][j], sg = sigmoidf_(x);
               v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
             }
           }
-          if (g.epi == EPI_RELU) {
+          if (epi == EPI_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
           }
-          if (g.epi == EPI_DRELU) {
+          if (epi == EPI_DRELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] *= pre[sl][ps][j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
           }
-          if (g.epi == EPI_RESID) {
+          if (epi == EPI_RESID) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = pre[sl][ps][j] + g.res_scale * v[j] * ds.mul((uint64_t)(ci + j));
           }
           *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
-          if (g.epi == EPI_SILU) {
+          if (epi == EPI_SILU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * ds.mul((uint64_t)(ci + j));
             *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
           }
-          if (g.epi == EPI_RELU_DROP) {
+          if (epi == EPI_RELU_DROP) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) v2[j] = fmaxf(v[j], 0.0f) * ds.mul((uint64_t)(ci + j));
             *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
@@ -435,16 +510,16 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
             if (j < nvalid) {
               float t = v[j];
               if (g.accumulate) t += C[ci + j];
-              if (g.epi == EPI_DSILU) {
+              if (epi == EPI_DSILU) {
                 const float x = aux[ci + j], sg = sigmoidf_(x);
                 t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
               }
-              if (g.epi == EPI_RELU) t = fmaxf(t, 0.0f);
-              if (g.epi == EPI_DRELU) t *= aux[ci + j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
-              if (g.epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
+              if (epi == EPI_RELU) t = fmaxf(t, 0.0f);
+              if (epi == EPI_DRELU) t *= aux[ci + j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
+              if (epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
               C[ci + j] = t;
-              if (g.epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
-              if (g.epi == EPI_RELU_DROP) C2[ci + j] = fmaxf(t, 0.0f) * ds.mul((uint64_t)(ci + j));
+              if (epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
+              if (epi == EPI_RELU_DROP) C2[ci + j] = fmaxf(t, 0.0f) * ds.mul((uint64_t)(ci + j));
             }
           }
         }
@@ -452,6 +527,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
     }
     __syncthreads();
   });
+#endif
+  EECT_STAMP(3);
 }
 
 template <int TM, int TN, int WGM, int WGN>
@@ -462,7 +539,12 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
 #ifndef EECT_STAGES
 #define EECT_STAGES 1  // measured on one box, default model: 1 -> 38.9 ms per step, 2 -> 40.6 ms, 2 for >= 32 k-tiles only -> 39.8 ms
 #endif
-#define EECT_GEMM(NP, AK, BK) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES>), grid, dim3(256), 0, st, g)
+  const bool fancy = g.epi != EPI_NONE && g.epi != EPI_RELU;
+#define EECT_GEMM(NP, AK, BK)                                                                                                   \
+  do {                                                                                                                          \
+    if (fancy) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, true>), grid, dim3(256), 0, st, g);   \
+    else hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, false>), grid, dim3(256), 0, st, g);        \
+  } while (0)
   if (np == 1) {
     if (akc && bkc) EECT_GEMM(1, true, true);
     else if (akc) EECT_GEMM(1, true, false);
