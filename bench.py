@@ -329,7 +329,7 @@ def main():
         tm = tm.to(dev).train()
         tm.train_passes = passes
         params = list(tm.parameters())
-        opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+        opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, fused=True)  # one multi-tensor kernel (torch's own)
         torch.manual_seed(rank)
 
         # gradients live in flat per-exit-group buckets; with N > 1 each bucket's RCCL all-reduce starts as the backward
@@ -628,7 +628,7 @@ def main():
                 fc.load_state_dict(synth.synth_state_dict(fc.state_dict(), seed=4, style="init"))
                 fc = fc.to(dev).train()
                 fparams = list(fc.parameters())
-                fopt = torch.optim.AdamW(fparams, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+                fopt = torch.optim.AdamW(fparams, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, fused=True)
                 ce = torch.nn.CrossEntropyLoss(ignore_index=126)
                 trg_in, trg_out = tgt[:, :-1].contiguous(), tgt[:, 1:].contiguous()
 

@@ -11,7 +11,7 @@ tm = Early_conformer(device="cuda", **bench.CFG)
 tm.load_state_dict(synth.synth_state_dict(tm.state_dict(), seed=2, style="init"))
 tm = tm.cuda().train(); tm.train_passes = 3
 params = list(tm.parameters())
-opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1)
+opt = torch.optim.AdamW(params, lr=1e-4, betas=(0.9, 0.98), eps=1e-9, weight_decay=0.1, **({'fused': True} if int(os.environ.get('EEC_FUSED_ADAMW', '0')) else {}))
 mel = synth.synth_mel(B, 80, T, seed=0).cuda(); lengths = torch.full((B,), T, dtype=torch.int64)
 tgt, tl = synth.synth_targets(B, 40, 256, seed=0); tgt, tl = tgt.cuda(), tl.cuda()
 def step(marks=None):
