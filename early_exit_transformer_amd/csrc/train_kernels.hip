@@ -232,11 +232,14 @@ extern "C" int eect_debug_tl(unsigned long long* out) {
 #define EECT_STAMP(i)
 #endif
 
-// FANCY: the epilogues with per-element arithmetic (SiLU / SiLU' / dropout / residual) are compiled in.  The plain form (bias,
-// alpha, accumulate, ReLU) is its own instantiation: with every variant in one body a slab's epilogue is 5.6 k instructions
-// (134 KB of code per tile against a 64 KB instruction cache shared by two CUs), and a plain K = 256 GEMM spent 30 k of its
-// workgroup's 65 k cycles there (tools/train_gemm_timeline.py).
-template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES, bool FANCY>
+// EPI_T selects what the epilogue is compiled for: kEpiPlain (bias, alpha, accumulate, ReLU), kEpiAny (every per-element epilogue
+// behind run-time switches: the fallback), or one of the EPI_* values alone.  With every variant in one body a 32-row slab's epilogue
+// is 5.6 k instructions (134 KB of code per tile against a 64 KB instruction cache shared by two CUs): a plain K = 256 GEMM spent
+// 30 k of its workgroup's 65 k cycles there (tools/train_gemm_timeline.py), 13.6 k in a body of its own.  The hot per-element
+// epilogues (SiLU second output, SiLU' x mask, residual + dropout) get bodies of their own for the tile shapes and layouts the
+// training plan uses them with.
+constexpr int kEpiPlain = -2, kEpiAny = -1;
+template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES, int EPI_T>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
@@ -386,8 +389,8 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // epilogue: the output tile leaves through LDS in slabs of 32 rows, so that every thread stores 16 contiguous bytes of a row
   // (an accumulator lane holds single columns: direct stores are 4-byte stores, four times as many instructions) and the
   // epilogue arithmetic runs on float4s.  The k-loop ended with a barrier: the planes are dead.
-  const int epi = FANCY ? g.epi : (g.epi == EPI_RELU ? EPI_RELU : EPI_NONE);
-  const DropState ds(FANCY ? g.drop : Drop{0.0f, 0, 0});
+  const int epi = EPI_T >= 0 ? EPI_T : EPI_T == kEpiAny ? g.epi : (g.epi == EPI_RELU ? EPI_RELU : EPI_NONE);
+  const DropState ds(EPI_T != kEpiPlain ? g.drop : Drop{0.0f, 0, 0});
   const float* __restrict__ aux = g.aux;
   float* __restrict__ C2 = g.C2;
 #if EECT_EPI_DIRECT
@@ -540,10 +543,32 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
 #define EECT_STAGES 1  // measured on one box, default model: 1 -> 38.9 ms per step, 2 -> 40.6 ms, 2 for >= 32 k-tiles only -> 39.8 ms
 #endif
   const bool fancy = g.epi != EPI_NONE && g.epi != EPI_RELU;
-#define EECT_GEMM(NP, AK, BK)                                                                                                   \
-  do {                                                                                                                          \
-    if (fancy) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, true>), grid, dim3(256), 0, st, g);   \
-    else hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, false>), grid, dim3(256), 0, st, g);        \
+  // bodies of their own: (epilogue, tile, layout) as the encoder's training plan launches them
+  constexpr bool big = TM == 2 && TN == 2 && WGM == 2 && WGN == 2, wide = TM == 2 && TN == 1 && WGM == 2 && WGN == 2;
+#define EECT_GEMM_E(NP, AK, BK, E) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, E>), grid, dim3(256), 0, st, g)
+  if constexpr (big || wide) {
+    if (akc && bkc && g.epi == EPI_RESID) {
+      if (np == 1) EECT_GEMM_E(1, true, true, EPI_RESID);
+      else EECT_GEMM_E(3, true, true, EPI_RESID);
+      return hipGetLastError();
+    }
+  }
+  if constexpr (big) {
+    if (akc && bkc && g.epi == EPI_SILU) {
+      if (np == 1) EECT_GEMM_E(1, true, true, EPI_SILU);
+      else EECT_GEMM_E(3, true, true, EPI_SILU);
+      return hipGetLastError();
+    }
+    if (akc && !bkc && g.epi == EPI_DSILU) {
+      if (np == 1) EECT_GEMM_E(1, true, false, EPI_DSILU);
+      else EECT_GEMM_E(3, true, false, EPI_DSILU);
+      return hipGetLastError();
+    }
+  }
+#define EECT_GEMM(NP, AK, BK)                          \
+  do {                                                 \
+    if (fancy) EECT_GEMM_E(NP, AK, BK, kEpiAny);       \
+    else EECT_GEMM_E(NP, AK, BK, kEpiPlain);           \
   } while (0)
   if (np == 1) {
     if (akc && bkc) EECT_GEMM(1, true, true);
@@ -557,6 +582,7 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
     else EECT_GEMM(3, false, false);
   }
 #undef EECT_GEMM
+#undef EECT_GEMM_E
   return hipGetLastError();
 }
 hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
@@ -572,6 +598,16 @@ hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
   if (wgs(128, 128) >= 384) return launch_gemm_t<2, 2, 2, 2>(g, np, st);
   return launch_gemm_t<1, 1, 2, 2>(g, np, st);  // 64 x 64
 }
+
+#ifdef EECT_TL
+// Diagnostic build only: one [M][N] = A . B^T launch with a per-element epilogue (tools/train_gemm_timeline.py)
+extern "C" int eect_debug_gemm_epi(const float* A, const float* B, float* C, const float* aux, float* C2, int M, int N, int K, int epi, int b_transposed,
+                                   float p, void* stream) {
+  GemmArgs g = gemm_args(A, K, 1, B, b_transposed ? 1 : K, b_transposed ? N : 1, C, N, M, N, K);
+  g.epi = epi, g.aux = aux, g.C2 = C2, g.drop = Drop{p, 1234, 7}, g.res_scale = 0.5f;
+  return (int)launch_gemm(g, 3, (hipStream_t)stream);
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LayerNorm

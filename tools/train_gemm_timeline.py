@@ -14,17 +14,30 @@ import torch  # noqa: E402
 lib = C.CDLL(os.environ["EEC_LIB"])
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
-for M, N, K, what in [(16384, 2048, 256, "ffn1"), (16384, 256, 2048, "ffn2"), (16384, 768, 256, "in_proj")]:
+lib.eect_debug_gemm_epi.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
+EPI = {"plain": 0, "silu (second output)": 1, "silu' x mask (reads aux)": 2, "residual + dropout (reads aux)": 4}
+cases = [(16384, 2048, 256, "ffn1", 3, "plain", 0), (16384, 2048, 256, "ffn1", 1, "plain", 0), (16384, 256, 2048, "ffn2", 3, "plain", 0),
+         (16384, 256, 2048, "ffn2", 1, "plain", 0), (16384, 768, 256, "in_proj", 3, "plain", 0), (16384, 768, 256, "in_proj", 1, "plain", 0),
+         (16384, 2048, 256, "ffn1 fwd", 3, "silu (second output)", 0), (16384, 2048, 256, "ffn dact, B transposed", 3, "plain", 1),
+         (16384, 2048, 256, "ffn dact, B transposed", 3, "silu' x mask (reads aux)", 1), (16384, 256, 2048, "ffn2 fwd", 3, "residual + dropout (reads aux)", 0)]
+for M, N, K, what, passes, epi, bt in cases:
     A = torch.randn(M, K, device="cuda")
-    B = torch.randn(N, K, device="cuda")
+    B = torch.randn(K, N, device="cuda") if bt else torch.randn(N, K, device="cuda")
     out = torch.empty(M, N, device="cuda")
-    for passes in (3, 1):
+    aux, out2 = torch.randn(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    what = f"{what}, epilogue {epi}"
+    if True:
+        def launch():
+            if epi == "plain" and not bt:
+                lib.eec_train_gemm(A.data_ptr(), B.data_ptr(), None, out.data_ptr(), M, N, K, passes, 0, 0, st)
+            else:
+                lib.eect_debug_gemm_epi(A.data_ptr(), B.data_ptr(), out.data_ptr(), aux.data_ptr(), out2.data_ptr(), M, N, K, EPI[epi], bt, 0.1, st)
         for _ in range(3):
-            lib.eec_train_gemm(A.data_ptr(), B.data_ptr(), None, out.data_ptr(), M, N, K, passes, 0, 0, st)
+            launch()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        lib.eec_train_gemm(A.data_ptr(), B.data_ptr(), None, out.data_ptr(), M, N, K, passes, 0, 0, st)
+        launch()
         e1.record()
         torch.cuda.synchronize()
         buf = (C.c_ulonglong * (64 * 16))()
