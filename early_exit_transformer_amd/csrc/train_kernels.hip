@@ -341,11 +341,19 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt) {
+#if EECT_EPI_DIRECT == 2
+          if (NP == 3) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], al[mt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+          }
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
+#else
           if (NP == 3) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#endif
         }
     }
 #ifdef EECT_TL
@@ -393,7 +401,91 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   const DropState ds(EPI_T != kEpiPlain ? g.drop : Drop{0.0f, 0, 0});
   const float* __restrict__ aux = g.aux;
   float* __restrict__ C2 = g.C2;
-#if EECT_EPI_DIRECT
+  const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
+  // one group of four consecutive columns of row m: v = alpha * acc + bias, the epilogue arithmetic, 16-byte stores
+  auto finish4 = [&](int m, int n, f32x4 a4, f32x4 pre4) __attribute__((always_inline)) {
+    const long ci = (long)m * g.c_m + n;
+    const int nvalid = min(4, g.N - n);
+    float v[4], v2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = g.alpha * a4[j] + ((g.bias && j < nvalid) ? g.bias[n + j] : 0.0f);
+    if (cvec) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] += g.accumulate ? pre4[j] : 0.0f;
+      if (epi == EPI_DSILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x = pre4[j], sg = sigmoidf_(x);
+          v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
+        }
+      }
+      if (epi == EPI_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+      }
+      if (epi == EPI_DRELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= pre4[j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
+      }
+      if (epi == EPI_RESID) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = pre4[j] + g.res_scale * v[j] * ds.mul((uint64_t)(ci + j));
+      }
+      *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
+      if (epi == EPI_SILU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * ds.mul((uint64_t)(ci + j));
+        *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+      }
+      if (epi == EPI_RELU_DROP) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v2[j] = fmaxf(v[j], 0.0f) * ds.mul((uint64_t)(ci + j));
+        *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j < nvalid) {
+          float t = v[j];
+          if (g.accumulate) t += C[ci + j];
+          if (epi == EPI_DSILU) {
+            const float x = aux[ci + j], sg = sigmoidf_(x);
+            t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
+          }
+          if (epi == EPI_RELU) t = fmaxf(t, 0.0f);
+          if (epi == EPI_DRELU) t *= aux[ci + j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
+          if (epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
+          C[ci + j] = t;
+          if (epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
+          if (epi == EPI_RELU_DROP) C2[ci + j] = fmaxf(t, 0.0f) * ds.mul((uint64_t)(ci + j));
+        }
+      }
+    }
+  };
+#if EECT_EPI_DIRECT == 2
+  // operands swapped in the k-loop: the accumulators hold the TRANSPOSED 32 x 32 tiles, i.e. lane l has row m = l % 32 and, per
+  // register quad q, the four consecutive columns 8 q + 4 (l / 32) ..: 16-byte stores straight from the registers, no LDS, no barrier
+  {
+    const bool want_pre = cvec && (g.accumulate || epi == EPI_DSILU || epi == EPI_RESID || epi == EPI_DRELU);
+    const float* __restrict__ pre_src = g.accumulate ? (const float*)C : aux;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int m = m0 + (wm * TM + mt) * 32 + (lane & 31), nb = n0 + (wn * TN + nt) * 32 + 4 * (lane >> 5);
+        f32x4 pre4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          pre4[q] = (want_pre && m < g.M && nb + 8 * q < g.N) ? *(const f32x4*)(pre_src + (long)m * g.c_m + nb + 8 * q) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = nb + 8 * q;
+          if (m < g.M && n < g.N)
+            finish4(m, n, (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]}, pre4[q]);
+        }
+      }
+  }
+#elif EECT_EPI_DIRECT
   // straight from the accumulators: for a fixed register index the 64 lanes of a wave hold two rows x 32 consecutive columns,
   // i.e. every store (and every load of old C / aux) instruction covers two full 128-byte segments -- no LDS round trip and no
   // barrier (the slab form below spent 13.6 k of a K = 256 workgroup's 47 k cycles on its 8 barriers)
@@ -436,7 +528,6 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   }
 #else
   float* slab = (float*)smem;
-  const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
   // what a slab's elements need from memory -- old C (accumulate) or aux (EPI_DSILU), never both -- is requested one slab
   // ahead: the loads of slab s + 1 are in flight while slab s goes through LDS and out
   constexpr int NPS = 32 * (BN / 4) / 256;
@@ -467,66 +558,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
     for (int ps = 0; ps < NPS; ++ps) {
       const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
       const int m = m0 + sl * 32 + row, n = n0 + c4;
-      if (m < g.M && n < g.N) {
-        const f32x4 a4 = *(const f32x4*)(slab + row * kSlabLd + c4);
-        const long ci = (long)m * g.c_m + n;
-        const int nvalid = min(4, g.N - n);
-        float v[4], v2[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = g.alpha * a4[j] + ((g.bias && j < nvalid) ? g.bias[n + j] : 0.0f);
-        if (cvec) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += g.accumulate ? pre[sl][ps][j] : 0.0f;
-          if (epi == EPI_DSILU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float x = pre[sl][ps][j], sg = sigmoidf_(x);
-              v[j] *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
-            }
-          }
-          if (epi == EPI_RELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-          }
-          if (epi == EPI_DRELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= pre[sl][ps][j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
-          }
-          if (epi == EPI_RESID) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = pre[sl][ps][j] + g.res_scale * v[j] * ds.mul((uint64_t)(ci + j));
-          }
-          *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
-          if (epi == EPI_SILU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * ds.mul((uint64_t)(ci + j));
-            *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
-          }
-          if (epi == EPI_RELU_DROP) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v2[j] = fmaxf(v[j], 0.0f) * ds.mul((uint64_t)(ci + j));
-            *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            if (j < nvalid) {
-              float t = v[j];
-              if (g.accumulate) t += C[ci + j];
-              if (epi == EPI_DSILU) {
-                const float x = aux[ci + j], sg = sigmoidf_(x);
-                t *= ds.mul((uint64_t)(ci + j)) * sg * (1.0f + x * (1.0f - sg));
-              }
-              if (epi == EPI_RELU) t = fmaxf(t, 0.0f);
-              if (epi == EPI_DRELU) t *= aux[ci + j] > 0.0f ? ds.mul((uint64_t)(ci + j)) : 0.0f;
-              if (epi == EPI_RESID) t = aux[ci + j] + g.res_scale * t * ds.mul((uint64_t)(ci + j));
-              C[ci + j] = t;
-              if (epi == EPI_SILU) C2[ci + j] = t * sigmoidf_(t) * ds.mul((uint64_t)(ci + j));
-              if (epi == EPI_RELU_DROP) C2[ci + j] = fmaxf(t, 0.0f) * ds.mul((uint64_t)(ci + j));
-            }
-          }
-        }
-      }
+      if (m < g.M && n < g.N) finish4(m, n, *(const f32x4*)(slab + row * kSlabLd + c4), pre[sl][ps]);
     }
     __syncthreads();
   });

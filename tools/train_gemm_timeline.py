@@ -16,7 +16,7 @@ st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.eec_train_gemm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
 lib.eect_debug_gemm_epi.argtypes = [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_float, C.c_void_p]
 EPI = {"plain": 0, "silu (second output)": 1, "silu' x mask (reads aux)": 2, "residual + dropout (reads aux)": 4}
-cases = [(16384, 2048, 256, "ffn1", 3, "plain", 0), (16384, 2048, 256, "ffn1", 1, "plain", 0), (16384, 256, 2048, "ffn2", 3, "plain", 0),
+cases = [(2048, 2048, 256, "ffn1 at M 2048 (C = 16 MB stays in the caches)", 3, "plain", 0), (16384, 2048, 256, "ffn1", 3, "plain", 0), (16384, 2048, 256, "ffn1", 1, "plain", 0), (16384, 256, 2048, "ffn2", 3, "plain", 0),
          (16384, 256, 2048, "ffn2", 1, "plain", 0), (16384, 768, 256, "in_proj", 3, "plain", 0), (16384, 768, 256, "in_proj", 1, "plain", 0),
          (16384, 2048, 256, "ffn1 fwd", 3, "silu (second output)", 0), (16384, 2048, 256, "ffn dact, B transposed", 3, "plain", 1),
          (16384, 2048, 256, "ffn dact, B transposed", 3, "silu' x mask (reads aux)", 1), (16384, 256, 2048, "ffn2 fwd", 3, "residual + dropout (reads aux)", 0)]
