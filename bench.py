@@ -199,9 +199,16 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    # EEC_BENCH_SINGLE_RANK=1 (N = 1 only): a process group of ONE rank on the real backend, every collective of the path issued
+    # through it (parallel.SINGLE_RANK_COLLECTIVES) -- what RCCL's call path costs a step on a box that has a single GPU
+    single_rank = world == 1 and os.environ.get("EEC_BENCH_SINGLE_RANK") == "1"
+    if world > 1 or single_rank:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if single_rank:
+            os.environ.setdefault("MASTER_PORT", "29577")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -209,6 +216,8 @@ def main():
 
     from early_exit_transformer_amd import parallel, synth
     from early_exit_transformer_amd.model import Early_conformer, exit_ctc_losses
+    if single_rank:
+        parallel.SINGLE_RANK_COLLECTIVES = True
 
     B, T = args.batch, args.frames
     model = Early_conformer(device=dev, **CFG).eval()
@@ -590,7 +599,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"early_conformer ctc 12-layer d_model=256 (6 exits x 2), batch {B}/GPU, mel [80 x {T}] -> T'={Tq}, log-normal synthetic mel, random-init weights (BASELINE.json configs[1])",
                        "global_batch": B * world, "mel_frames": T, "parallelism": f"dp{world} (utterance-batch shards)",
-                       "precision_mode": args.precision},
+                       "precision_mode": args.precision,
+                       **({"single_rank_rehearsal": f"every collective of the path issued through a process group of ONE rank on backend {backend!r} (EEC_BENCH_SINGLE_RANK=1)"} if single_rank else {})},
             "parity": parity,
             "frac_of_mfma_peak_whole_forward": round(flop_fwd * world * args.steps / dt / (MFMA_PEAK_FLOPS * world), 4),
             "algorithmic_flop_per_mel_frame": round(flop_fwd / (B * T), 1),

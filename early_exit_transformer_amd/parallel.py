@@ -13,6 +13,7 @@ collective runs on RCCL's stream under the backward of group e - 1.  Nothing on 
 data or reads one back (no ``torch.tensor(...)``, no ``.item()``): the shard sizes are exchanged once and cached."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
@@ -28,8 +29,16 @@ def shard_range(n: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# Rehearsal switch (EEC_DP_SINGLE_RANK=1, or set the attribute): a process group of ONE rank counts as active, so that on a
+# one-GPU box every collective of the path still goes through the backend -- RCCL's stream hand-over, its work objects, the
+# bucket bookkeeping -- with nothing to exchange.  Results are those of the single-GPU step (weight 1, sum over one rank).
+SINGLE_RANK_COLLECTIVES = os.environ.get("EEC_DP_SINGLE_RANK") == "1"
+
+
 def _active(group) -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or SINGLE_RANK_COLLECTIVES
 
 
 # (device, b_local) -> device-resident [b_local] fp32: built once, so a step never pays a blocking pageable host -> device

@@ -287,6 +287,60 @@ def test_world2_data_parallel_training_step_on_the_product_path():
     assert worst < 1e-5, worst
 
 
+def _rccl_single_rank(port, q):
+    import os
+    import torch.distributed as dist
+    from early_exit_transformer_amd import parallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        parallel.SINGLE_RANK_COLLECTIVES = True
+        kw = base_kwargs(**SMALL)
+        _, gpu = make_train_pair(kw, seed=61)
+        B, T = 4, 131
+        mel, lens = synth.synth_mel(B, 80, T, seed=61).cuda(), torch.tensor([131, 90, 57, 131])
+        tgt, tl = synth.synth_targets(B, 9, kw["dec_voc_size"], seed=61)
+
+        def step():
+            gpu.zero_grad(set_to_none=True)
+            for m in gpu.modules():
+                if isinstance(m, torch.nn.BatchNorm1d):
+                    m.reset_running_stats()
+            losses = exit_ctc_losses(gpu(mel, lens), tgt, tl)
+            losses.sum().backward()
+            return parallel.combine_exit_losses(losses.detach(), B)
+
+        parallel.SINGLE_RANK_COLLECTIVES = False
+        l0 = step()
+        plain = {n: p.grad.clone() for n, p in gpu.named_parameters()}
+        parallel.SINGLE_RANK_COLLECTIVES = True
+        gpu.enable_data_parallel(B, min_bucket_bytes=0)
+        l1 = step()  # the buckets' all-reduces leave from the backward's callback, through RCCL, with one rank
+        n_coll = gpu.sync_gradients()
+        torch.cuda.synchronize()
+        same = all(torch.equal(p.grad, plain[n]) for n, p in gpu.named_parameters())
+        q.put((n_coll, same, torch.allclose(l0, l1, rtol=1e-6, atol=0), dist.get_backend()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_rank_rccl_runs_every_collective_of_the_training_step():
+    """The real backend on a one-GPU box: a process group of ONE rank on "nccl" (= RCCL), parallel.SINGLE_RANK_COLLECTIVES, and
+    the data-parallel training step of the product module.  The shard-size exchange, the loss all-reduce and the three bucket
+    all-reduces (started from eec_train_backward_ex's callback, joined by sync_gradients) all go through RCCL's work objects
+    and stream hand-over; with one rank the results must be those of the plain step, bit for bit."""
+    import os
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_rank, args=(37500 + os.getpid() % 2000, q))
+    p.start()
+    n_coll, same, loss_ok, backend = q.get(timeout=300)
+    p.join(120)
+    assert p.exitcode == 0
+    assert backend == "nccl" and n_coll == 3 and same and loss_ok
+
+
 @pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2)], ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention"])
 def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     """drop_prob > 0: streams cannot match torch's, so the check is internal -- the same seed reproduces the step, another
