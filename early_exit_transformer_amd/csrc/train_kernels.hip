@@ -962,71 +962,164 @@ hipError_t launch_glu_bwd(const float* dg, const float* u, float* du, int M, int
 // depthwise conv over time
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int kDwMaxK = 31;
-constexpr int kDwRows = 16;  // time steps per block
-constexpr int kDwStep = 4;   // outputs per thread and window load
+#ifndef EECT_DW_ROWS
+#define EECT_DW_ROWS 32
+#endif
+#ifndef EECT_DW_STEP
+#define EECT_DW_STEP 32
+#endif
+constexpr int kDwRows = EECT_DW_ROWS;  // time steps per block
+constexpr int kDwStep = EECT_DW_STEP;  // outputs per thread and window load
 // y[b][t][d] = bias[d] + sum_j w[d][FLIP ? K-1-j : j] * x[b][t + j - pad][d]; a thread owns channel d and produces kDwStep
-// consecutive outputs from one K + kDwStep - 1 long window of x (loads are coalesced over d)
+// consecutive outputs from one K + kDwStep - 1 long window of x (loads are coalesced over d).
+// Two forms.  The FAST one (K = 31, the block of kDwStep rows is the first / an interior / the last one of its utterance) knows at
+// compile time which window rows exist: no bounds logic at all, 62 (47 at the ends) independent loads and 992 multiply-adds per
+// thread.  The GENERIC one (any K, ragged ends) clamps the row index and zeroes afterwards.  In both the row index is made per-lane
+// on purpose (an opaque zero in a VGPR): left uniform, the compiler keeps one 64-bit row address -- and one mask -- per window row
+// in SGPRs and spills hundreds of them (the first form of these kernels: 5 k instructions, 1.1 k of them SGPR spill traffic, for 1 k
+// multiply-adds; 38 / 42 / 70 us per launch at the default model).
+__device__ __forceinline__ int opaque_zero() {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
+constexpr int kDwPad = (kDwMaxK - 1) / 2, kDwWin = kDwMaxK + kDwStep - 1;
+// EDGE: 0 interior, 1 the rows before the utterance are missing (t == 0), 2 the rows behind it are (t + kDwStep == T)
+template <int EDGE>
+__device__ __forceinline__ constexpr bool dw_have(int i) {
+  return !(EDGE == 1 && i < kDwPad) && !(EDGE == 2 && i >= kDwStep + kDwPad);
+}
+template <int EDGE>
+__device__ __forceinline__ void dw_window_fast(float (&win)[kDwWin], const float* __restrict__ utt, int d, int t, int D, int z) {
+#pragma unroll
+  for (int i = 0; i < kDwWin; ++i) {
+    if (dw_have<EDGE>(i)) win[i] = utt[(unsigned)((t - kDwPad + i + z) * D + d)];
+    else win[i] = 0.0f;
+  }
+}
+// 0 / 1 / 2: the fast form applies with that EDGE; -1: generic
+__device__ __forceinline__ int dw_edge(int t, int T, int K) {
+  if (K != kDwMaxK) return -1;
+  if (t - kDwPad >= 0 && t + kDwStep + kDwPad <= T) return 0;
+  if (t == 0 && kDwStep + kDwPad <= T) return 1;
+  if (t + kDwStep == T && t - kDwPad >= 0) return 2;
+  return -1;
+}
+template <int W>
+__device__ __forceinline__ void dw_window_generic(float (&win)[W], const float* __restrict__ utt, int d, int t_first, int T, int D, int wlen, int z) {
+#pragma unroll
+  for (int j = 0; j < W; ++j) {
+    const int tt = t_first + j + z, tc = min(max(tt, 0), T - 1);
+    const float v = utt[(unsigned)(tc * D + d)];
+    win[j] = (tt == tc && j < wlen) ? v : 0.0f;
+  }
+}
 template <bool FLIP>
 __global__ __launch_bounds__(256) void dw_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                  float* __restrict__ y, int T, int D, int K) {
   const int b = blockIdx.y, t0 = blockIdx.x * kDwRows, pad = (K - 1) / 2;
+  const float* __restrict__ utt = x + (long)b * T * D;
+  float* __restrict__ yutt = y + (long)b * T * D;
   for (int d = threadIdx.x; d < D; d += 256) {
     float wt[kDwMaxK];
 #pragma unroll
-    for (int j = 0; j < kDwMaxK; ++j) wt[j] = j < K ? w[(long)d * K + (FLIP ? K - 1 - j : j)] : 0.0f;
+    for (int j = 0; j < kDwMaxK; ++j) {
+      const float v = w[(long)d * K + (j < K ? (FLIP ? K - 1 - j : j) : 0)];
+      wt[j] = j < K ? v : 0.0f;
+    }
     const float bv = bias ? bias[d] : 0.0f;
-    for (int t = t0; t < min(T, t0 + kDwRows); t += kDwStep) {
-      float win[kDwMaxK + kDwStep - 1];
+    const int t_end = min(T, t0 + kDwRows), z = opaque_zero();
+    for (int t = t0; t < t_end; t += kDwStep) {
+      float win[kDwWin];
+      auto fast = [&](auto edge_tag) __attribute__((always_inline)) {
+        constexpr int EDGE = decltype(edge_tag)::value;
+        dw_window_fast<EDGE>(win, utt, d, t, D, z);
 #pragma unroll
-      for (int j = 0; j < kDwMaxK + kDwStep - 1; ++j) {
-        const int tt = t + j - pad;
-        win[j] = (j < K + kDwStep - 1 && tt >= 0 && tt < T) ? x[((long)b * T + tt) * D + d] : 0.0f;
-      }
+        for (int o = 0; o < kDwStep; ++o) {
+          float s = bv;
 #pragma unroll
-      for (int o = 0; o < kDwStep; ++o) {
-        float s = bv;
+          for (int j = 0; j < kDwMaxK; ++j)
+            if (dw_have<EDGE>(o + j)) s += wt[j] * win[o + j];
+          yutt[(unsigned)((t + o + z) * D + d)] = s;
+        }
+      };
+      const int edge = dw_edge(t, T, K);  // uniform
+      if (edge == 0) fast(IntTag<0>{});
+      else if (edge == 1) fast(IntTag<1>{});
+      else if (edge == 2) fast(IntTag<2>{});
+      else {
+        dw_window_generic(win, utt, d, t - pad, T, D, K + kDwStep - 1, z);
 #pragma unroll
-        for (int j = 0; j < kDwMaxK; ++j) s += wt[j] * win[j + o];
-        if (t + o < T) y[((long)b * T + t + o) * D + d] = s;
+        for (int o = 0; o < kDwStep; ++o) {
+          float s = bv;
+#pragma unroll
+          for (int j = 0; j < kDwMaxK; ++j) s += wt[j] * win[j + o];
+          if (t + o < t_end) yutt[(unsigned)((t + o + z) * D + d)] = s;
+        }
       }
     }
   }
 }
 hipError_t launch_dw_fwd(const float* x, const float* w, const float* b, float* y, int B, int T, int D, int K, hipStream_t st) {
-  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  if (K > kDwMaxK || !(K & 1) || (long)T * D >= (1l << 30)) return hipErrorInvalidValue;  // 32-bit element offsets inside an utterance
   hipLaunchKernelGGL(dw_kernel<false>, dim3((T + kDwRows - 1) / kDwRows, B), dim3(256), 0, st, x, w, b, y, T, D, K);
   return hipGetLastError();
 }
 hipError_t launch_dw_bwd_data(const float* dy, const float* w, float* dx, int B, int T, int D, int K, hipStream_t st) {
-  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  if (K > kDwMaxK || !(K & 1) || (long)T * D >= (1l << 30)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(dw_kernel<true>, dim3((T + kDwRows - 1) / kDwRows, B), dim3(256), 0, st, dy, w, (const float*)nullptr, dx, T, D, K);
   return hipGetLastError();
 }
-constexpr int kDwwRows = 64;
+#ifndef EECT_DWW_ROWS
+#define EECT_DWW_ROWS 64
+#endif
+constexpr int kDwwRows = EECT_DWW_ROWS;
+static_assert(kDwRows % kDwStep == 0 && kDwwRows % kDwStep == 0, "blocks are whole steps");
 int dw_bwd_weight_blocks(int B, int T) { return B * ((T + kDwwRows - 1) / kDwwRows); }
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
                                                             int T, int D, int K) {
   const int nchunk = (T + kDwwRows - 1) / kDwwRows, b = blockIdx.x / nchunk, t0 = (blockIdx.x % nchunk) * kDwwRows, pad = (K - 1) / 2;
+  const float* __restrict__ xutt = x + (long)b * T * D;
+  const float* __restrict__ gutt = dy + (long)b * T * D;
   for (int d = threadIdx.x; d < D; d += 256) {
     float acc[kDwMaxK + 1];
 #pragma unroll
     for (int j = 0; j <= kDwMaxK; ++j) acc[j] = 0.0f;
-    for (int t = t0; t < min(T, t0 + kDwwRows); t += kDwStep) {
-      float win[kDwMaxK + kDwStep - 1], g[kDwStep];
+    const int t_end = min(T, t0 + kDwwRows), z = opaque_zero();
+    for (int t = t0; t < t_end; t += kDwStep) {
+      float win[kDwWin], g[kDwStep];
+      auto fast = [&](auto edge_tag) __attribute__((always_inline)) {
+        constexpr int EDGE = decltype(edge_tag)::value;
+        dw_window_fast<EDGE>(win, xutt, d, t, D, z);
 #pragma unroll
-      for (int j = 0; j < kDwMaxK + kDwStep - 1; ++j) {
-        const int tt = t + j - pad;
-        win[j] = (j < K + kDwStep - 1 && tt >= 0 && tt < T) ? x[((long)b * T + tt) * D + d] : 0.0f;
+        for (int o = 0; o < kDwStep; ++o) {
+          g[o] = gutt[(unsigned)((t + o + z) * D + d)];
+          acc[kDwMaxK] += g[o];
+        }
+#pragma unroll
+        for (int j = 0; j < kDwMaxK; ++j)
+#pragma unroll
+          for (int o = 0; o < kDwStep; ++o)
+            if (dw_have<EDGE>(o + j)) acc[j] += g[o] * win[o + j];
+      };
+      const int edge = dw_edge(t, T, K);  // uniform
+      if (edge == 0) fast(IntTag<0>{});
+      else if (edge == 1) fast(IntTag<1>{});
+      else if (edge == 2) fast(IntTag<2>{});
+      else {
+        dw_window_generic(win, xutt, d, t - pad, T, D, K + kDwStep - 1, z);
+#pragma unroll
+        for (int o = 0; o < kDwStep; ++o) {
+          const int tg = t + o + z;
+          const float v = gutt[(unsigned)(min(tg, T - 1) * D + d)];
+          g[o] = tg < t_end ? v : 0.0f;
+          acc[kDwMaxK] += g[o];
+        }
+#pragma unroll
+        for (int j = 0; j < kDwMaxK; ++j)
+#pragma unroll
+          for (int o = 0; o < kDwStep; ++o) acc[j] += g[o] * win[j + o];
       }
-#pragma unroll
-      for (int o = 0; o < kDwStep; ++o) {
-        g[o] = t + o < min(T, t0 + kDwwRows) ? dy[((long)b * T + t + o) * D + d] : 0.0f;
-        acc[kDwMaxK] += g[o];
-      }
-#pragma unroll
-      for (int j = 0; j < kDwMaxK; ++j)
-#pragma unroll
-        for (int o = 0; o < kDwStep; ++o) acc[j] += g[o] * win[j + o];
     }
 #pragma unroll
     for (int j = 0; j < kDwMaxK; ++j)
@@ -1043,7 +1136,7 @@ __global__ __launch_bounds__(256) void dw_weight_finalize_kernel(const float* __
   else db[d] = tot[i];
 }
 hipError_t launch_dw_bwd_weight(const float* dy, const float* x, float* part, float* dw, float* db, int B, int T, int D, int K, hipStream_t st) {
-  if (K > kDwMaxK || !(K & 1)) return hipErrorInvalidValue;
+  if (K > kDwMaxK || !(K & 1) || (long)T * D >= (1l << 30)) return hipErrorInvalidValue;
   const int S = dw_bwd_weight_blocks(B, T);
   const long n = (long)(K + 1) * D;
   float* tot = part + (size_t)S * n;  // [K + 1][D] behind the partials
@@ -1100,6 +1193,7 @@ __global__ __launch_bounds__(256) void bn_silu_bwd_sums_kernel(const float* __re
   for (int ch = threadIdx.x; ch < D; ch += 256) {
     const float mu = stats[ch], rs = stats[D + ch], gg = g[ch], bb = b[ch];
     float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll 8  // eight rows' loads in flight (rolled, every row is its own round trip: 31 us per launch against 7 us of traffic)
     for (int r = r_begin; r < r_end; ++r) {
       const float xh = (c[(long)r * D + ch] - mu) * rs, y = xh * gg + bb, sg = sigmoidf_(y);
       const float dy = ds[(long)r * D + ch] * sg * (1.0f + y * (1.0f - sg));
