@@ -685,7 +685,10 @@ hipError_t launch_ln_fwd(const float* x, const float* g, const float* b, float* 
   return hipGetLastError();
 }
 
-int ln_bwd_blocks(int M) { return max(1, min(1024, (M + 7) / 8)); }
+#ifndef EECT_LN_BLOCKS
+#define EECT_LN_BLOCKS 1024
+#endif
+int ln_bwd_blocks(int M) { return max(1, min(EECT_LN_BLOCKS, (M + 7) / 8)); }
 template <int NE>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ g,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
