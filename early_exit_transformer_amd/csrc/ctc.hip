@@ -369,19 +369,25 @@ hipError_t launch_ctc_backward(const float* logp, const long long* targets, cons
   return hipGetLastError();
 }
 
-// loss_e = mean_b( zero_inf(nll[e][b]) / max(len_b, 1) ): fixed summation order (bitwise reproducible)
+// loss_e = mean_b( zero_inf(nll[e][b]) / max(len_b, 1) ): fixed summation order (bitwise reproducible).  The 64 lanes fetch 64
+// utterances' terms at once; lane order is then added up sequentially out of registers (one thread walking the batch with two
+// dependent loads per utterance took 10.7 us per launch: 0.4 % of the headline step).
 __global__ void ctc_reduce_kernel(const float* nll, const long long* target_len, int B, float* out) {
-  const int e = blockIdx.x;
-  if (threadIdx.x == 0) {
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  float s = 0.f;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + lane;
+    float term = 0.f;
+    if (b < B) {
       float v = nll[e * B + b];
       if (isinf(v)) v = 0.f;  // zero_infinity=True zeroes infinite losses only: NaN (bad input) propagates
       const long long l = target_len[b] > 0 ? target_len[b] : 1;
-      s += v / (float)l;
+      term = v / (float)l;
     }
-    out[e] = s / (float)B;
+    const int n = min(64, B - b0);
+    for (int i = 0; i < n; ++i) s += __shfl(term, i, 64);
   }
+  if (lane == 0) out[e] = s / (float)B;
 }
 
 hipError_t launch_ctc_loss(const float* logp, const long long* targets, const long long* target_len, int E, int B, int Tq,
