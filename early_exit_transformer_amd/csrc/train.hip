@@ -153,7 +153,8 @@ void linear_bwd_weight(Run& r, const float* dy, const float* x, float* dW, float
   const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
   // splits: enough workgroups for two per CU, but at least 8 k-tiles (256 rows) per split -- with 128-row splits a 256 x 256 weight
   // gradient was 128 partials of 263 KB (34 MB written and read back for a 2 GFLOP product) and 4 k-tiles per workgroup
-  int S = std::max(1, std::min(512 / tiles, M >= 4096 ? M / 256 : M / 64));
+  static const int wg_target = [] { const char* e = getenv("EEC_TRAIN_DW_WGS"); return e ? atoi(e) : 512; }();  // tuning knob
+  int S = std::max(1, std::min(wg_target / tiles, M >= 4096 ? M / 256 : M / 64));
   int chunk = ((M + S - 1) / S + 31) / 32 * 32;
   S = (M + chunk - 1) / chunk;
   hipStream_t ws = r.side ? r.side : r.st;
