@@ -482,7 +482,7 @@ def main():
     # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
     # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
     if roofline is not None and args.precision == "f16f8":
-        pmc = os.path.join(ROOT, "profiles", "r03_a_pmc_chain_kernel_f16f8.txt")
+        pmc = os.path.join(ROOT, "profiles", "r03_c_pmc_chain_kernel_f16f8.txt")
         if os.path.exists(pmc):
             fetch, write = [], []
             for ln in open(pmc):
@@ -492,7 +492,7 @@ def main():
                     write.append(float(ln.split("avg/dispatch")[1].split()[0]))
             if fetch and write:
                 roofline["traffic"] = round((2.0 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024.0)
-                roofline["traffic_source"] = ("STATIC evidence, not measured in this run: profiles/r03_a_pmc_chain_kernel_f16f8.txt "
+                roofline["traffic_source"] = ("STATIC evidence, not measured in this run: profiles/r03_c_pmc_chain_kernel_f16f8.txt "
                                               "(rocprofv3 --pmc passes of this build; 2*FETCH_SIZE + WRITE_SIZE, KiB -> B; the "
                                               "two-stage variant = 11 of the 13 launches)")
 
