@@ -79,6 +79,10 @@ def compare_grads(got, want, tol, label):
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=2, d_feed_forward=256, depthwise_kernel_size=31), 2, 99, [99, 64]),
     (dict(SMALL, n_head=2), 2, 47, [47, 30]),  # T' = 11: fused attention with a single, ragged key tile
     (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=64), 1, 51, [51]),  # a single utterance: BatchNorm over its 12 frames
+    # T' = 100 with 31 taps: the depthwise kernels' first / interior blocks take the compile-time forms, the last full block and the
+    # 4-row remainder the generic one
+    (dict(SMALL, n_head=2, depthwise_kernel_size=31), 2, 403, [403, 250]),
+    (dict(SMALL, n_head=2, depthwise_kernel_size=31), 1, 259, [259]),  # T' = 64: a first and a last block, nothing between
     # the benchmark's frame count (T' = 256: two query / key blocks of the fused attention per head, eight key tiles, ragged keys)
     (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 700]),
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 513]),
