@@ -254,14 +254,23 @@ extern "C" int eect_debug_tl(unsigned long long* out) {
 // epilogues (SiLU second output, SiLU' x mask, residual + dropout) get bodies of their own for the tile shapes and layouts the
 // training plan uses them with.
 constexpr int kEpiPlain = -2, kEpiAny = -1;
+// LDS of one workgroup: the operand plane sets of the k-loop, reused as a [32][BN + 4] fp32 slab of the output tile in the epilogue
+template <int TM, int TN, int WGM, int WGN, int NP, int STAGES>
+constexpr int gemm_lds_bytes() {
+  constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
+  constexpr int planes = (STAGES == 3 ? 2 : 1) * (NP == 3 ? 2 : 1) * (TileGeo<BM>::kElems + TileGeo<BN>::kElems) * 2;
+  constexpr int slab = 32 * (BN + 4) * 4, red = 4 * 256 * 4;  // red: the row-sum reduction's [256 / (BM / 4)][BM] floats
+  return planes > slab ? (planes > red ? planes : red) : (slab > red ? slab : red);
+}
 template <int TM, int TN, int WGM, int WGN, int NP, bool AKC, bool BKC, int STAGES, int EPI_T>
 __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs g) {
   static_assert(WGM * WGN == 4, "4 waves");
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   // one LDS block: the operand planes during the k-loop, a [32][BN + 4] fp32 slab of the output tile in the epilogue
   constexpr int EA = TileGeo<BM>::kElems, EB = TileGeo<BN>::kElems, kSlabLd = BN + 4;
-  constexpr int kPlaneBytes = (NP == 3 ? 2 : 1) * (EA + EB) * 2, kSlabBytes = 32 * kSlabLd * 4;
-  __shared__ __attribute__((aligned(16))) char smem[kPlaneBytes > kSlabBytes ? kPlaneBytes : kSlabBytes];
+  constexpr int kPlaneBytes = (NP == 3 ? 2 : 1) * (EA + EB) * 2;
+  // STAGES == 3: two plane sets, one barrier per k-tile (below); the block is dynamic LDS (gemm_lds_bytes: 80 KB at 128 x 128 x 3)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16* a_hi = (bf16*)smem;
   bf16* b_hi = a_hi + EA;
   bf16* a_lo = NP == 3 ? b_hi + EB : a_hi;
@@ -323,7 +332,9 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // (its BM / 32 groups of four all belong to the same four rows: 256 % (BM / 4) == 0)
   float rs[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   const bool do_rs = !AKC && g.rowsum != nullptr && bx == 0;
-  auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
+  constexpr int kBufElems = kPlaneBytes / 2;  // bf16 elements between the two plane sets
+  // registers -> (split) -> plane set `buf`
+  auto split_store = [&](float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], int buf) __attribute__((always_inline)) {
     if constexpr (!AKC) {
       if (do_rs) {
 #pragma unroll
@@ -332,25 +343,23 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           for (int j = 0; j < 4; ++j) rs[j] += ra[it][j];
       }
     }
-    store_tile<BM, NP, AKC>(a_hi, a_lo, ra, tid);
-    store_tile<BN, NP, BKC>(b_hi, b_lo, rb, tid);
-    __syncthreads();
-#ifdef EECT_TL
-    if (kt < 4) EECT_STAMP(4 + 2 * kt);
-#endif
-    if (kt + STAGES < nk) load_ab(ra, rb, k_of(kt + STAGES), fast_tag);
+    store_tile<BM, NP, AKC>(a_hi + buf * kBufElems, a_lo + buf * kBufElems, ra, tid);
+    store_tile<BN, NP, BKC>(b_hi + buf * kBufElems, b_lo + buf * kBufElems, rb, tid);
+  };
+  // the 32-deep k-tile in plane set `buf`: fragments from LDS, 4 x TM x TN x (1 or 3) MFMAs
+  auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt) {
-        ah[mt] = read_frag<BM, AKC>(a_hi, (wm * TM + mt) * 32, ks, lane);
-        if (NP == 3) al[mt] = read_frag<BM, AKC>(a_lo, (wm * TM + mt) * 32, ks, lane);
+        ah[mt] = read_frag<BM, AKC>(a_hi + buf * kBufElems, (wm * TM + mt) * 32, ks, lane);
+        if (NP == 3) al[mt] = read_frag<BM, AKC>(a_lo + buf * kBufElems, (wm * TM + mt) * 32, ks, lane);
       }
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
-        bh[nt] = read_frag<BN, BKC>(b_hi, (wn * TN + nt) * 32, ks, lane);
-        if (NP == 3) bl[nt] = read_frag<BN, BKC>(b_lo, (wn * TN + nt) * 32, ks, lane);
+        bh[nt] = read_frag<BN, BKC>(b_hi + buf * kBufElems, (wn * TN + nt) * 32, ks, lane);
+        if (NP == 3) bl[nt] = read_frag<BN, BKC>(b_lo + buf * kBufElems, (wn * TN + nt) * 32, ks, lane);
       }
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
@@ -371,15 +380,45 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
 #endif
         }
     }
+  };
+  auto k_tile = [&](int kt, float (&ra)[BM / 32][4], float (&rb)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
+    split_store(ra, rb, 0);
+    __syncthreads();
+#ifdef EECT_TL
+    if (kt < 4) EECT_STAMP(4 + 2 * kt);
+#endif
+    if (kt + STAGES < nk) load_ab(ra, rb, k_of(kt + STAGES), fast_tag);
+    mfma_tile(0);
 #ifdef EECT_TL
     if (kt < 4) EECT_STAMP(5 + 2 * kt);
 #endif
     __syncthreads();
   };
+  // STAGES == 3, the pipelined form: two plane sets in LDS and two register sets.  While the MFMAs run on plane set kt % 2 the
+  // same wave splits tile kt + 1 (already in registers) into the other set, and tile kt + 2's loads are in flight: ONE barrier per
+  // k-tile, and the split's VALU work sits in the shadow of the MFMAs of the same wave instead of in a phase of its own.
+  auto pipe_step = [&](int kt, int buf, float (&r_next_a)[BM / 32][4], float (&r_next_b)[BN / 32][4], float (&r_load_a)[BM / 32][4],
+                       float (&r_load_b)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
+    if (kt + 2 < nk) load_ab(r_load_a, r_load_b, k_of(kt + 2), fast_tag);  // into the set whose tile went to LDS a step ago
+    mfma_tile(buf);
+    if (kt + 1 < nk) split_store(r_next_a, r_next_b, buf ^ 1);
+#ifdef EECT_TL
+    if (kt < 4) EECT_STAMP(4 + 2 * kt), EECT_STAMP(5 + 2 * kt);
+#endif
+    __syncthreads();  // set buf ^ 1 complete; everybody done with set buf
+  };
   auto k_loop = [&](auto fast_tag) __attribute__((always_inline)) {
     load_ab(ra0, rb0, k_of(0), fast_tag);
     if constexpr (STAGES == 1) {
       for (int kt = 0; kt < nk; ++kt) k_tile(kt, ra0, rb0, fast_tag);
+    } else if constexpr (STAGES == 3) {
+      if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
+      split_store(ra0, rb0, 0);
+      __syncthreads();
+      for (int kt = 0; kt < nk; kt += 2) {
+        pipe_step(kt, 0, ra1, rb1, ra0, rb0, fast_tag);
+        if (kt + 1 < nk) pipe_step(kt + 1, 1, ra0, rb0, ra1, rb1, fast_tag);
+      }
     } else {
       if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
       for (int kt = 0; kt < nk; kt += 2) {
@@ -594,7 +633,19 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
   const bool fancy = g.epi != EPI_NONE && g.epi != EPI_RELU;
   // bodies of their own: (epilogue, tile, layout) as the encoder's training plan launches them
   constexpr bool big = TM == 2 && TN == 2 && WGM == 2 && WGN == 2, wide = TM == 2 && TN == 1 && WGM == 2 && WGN == 2;
-#define EECT_GEMM_E(NP, AK, BK, E) hipLaunchKernelGGL((gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, E>), grid, dim3(256), 0, st, g)
+#define EECT_GEMM_E(NP, AK, BK, E)                                                                              \
+  do {                                                                                                          \
+    auto kfn = gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, E>;                                       \
+    constexpr int lds = gemm_lds_bytes<TM, TN, WGM, WGN, NP, EECT_STAGES>();                                    \
+    if (lds > 65536) {                                                                                          \
+      static bool raised = false; /* per instantiation */                                                       \
+      if (!raised) {                                                                                            \
+        if (hipError_t e_ = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, lds); e_ != hipSuccess) return e_; \
+        raised = true;                                                                                          \
+      }                                                                                                         \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, g);                                                       \
+  } while (0)
   if constexpr (big || wide) {
     if (akc && bkc && g.epi == EPI_RESID) {
       if (np == 1) EECT_GEMM_E(1, true, true, EPI_RESID);
