@@ -228,6 +228,9 @@ enum { EPI_NONE = 0, EPI_SILU = 1, EPI_DSILU = 2, EPI_RELU = 3, EPI_RESID = 4, E
 
 // STAGES: register prefetch depth of the k-loop.  2: the loads of tile kt + 2 are in flight across two MFMA phases (long
 // contractions); 1: 64 registers fewer, so that three workgroups share a CU (short contractions, many tiles: +25-50 %)
+#ifndef EECT_PIPE_SCHED
+#define EECT_PIPE_SCHED 7  // STAGES == 3 only: VALU instructions placed behind every MFMA of the interval (0: the compiler's order)
+#endif
 #ifndef EECT_EPI_DIRECT
 #define EECT_EPI_DIRECT 0  // 1: 4-byte stores straight from the accumulators (measured: epilogue 23.5 k cycles against 13.6 k through the slabs)
 #endif
@@ -397,11 +400,30 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   // STAGES == 3, the pipelined form: two plane sets in LDS and two register sets.  While the MFMAs run on plane set kt % 2 the
   // same wave splits tile kt + 1 (already in registers) into the other set, and tile kt + 2's loads are in flight: ONE barrier per
   // k-tile, and the split's VALU work sits in the shadow of the MFMAs of the same wave instead of in a phase of its own.
+  // steady_tag: both tiles ahead exist -- no conditions, so that the interval is ONE basic block (the scheduling hints below only
+  // reorder inside one)
   auto pipe_step = [&](int kt, int buf, float (&r_next_a)[BM / 32][4], float (&r_next_b)[BN / 32][4], float (&r_load_a)[BM / 32][4],
-                       float (&r_load_b)[BN / 32][4], auto fast_tag) __attribute__((always_inline)) {
-    if (kt + 2 < nk) load_ab(r_load_a, r_load_b, k_of(kt + 2), fast_tag);  // into the set whose tile went to LDS a step ago
+                       float (&r_load_b)[BN / 32][4], auto fast_tag, auto steady_tag) __attribute__((always_inline)) {
+    constexpr bool steady = decltype(steady_tag)::value;
+    if (steady || kt + 2 < nk) load_ab(r_load_a, r_load_b, k_of(kt + 2), fast_tag);  // into the set whose tile went to LDS a step ago
     mfma_tile(buf);
-    if (kt + 1 < nk) split_store(r_next_a, r_next_b, buf ^ 1);
+    if (steady || kt + 1 < nk) split_store(r_next_a, r_next_b, buf ^ 1);
+#if EECT_PIPE_SCHED
+    // the interval as one interleaved stream: fragment reads of a k-step, then its MFMAs with the split's VALU work and LDS stores
+    // in their shadows (hipcc otherwise emits the MFMAs and the split as two blocks)
+    {
+      constexpr int kMfma = 2 * TM * TN * (NP == 3 ? 3 : 1), kReads = (NP == 3 ? 2 : 1) * (TM + TN) * ((AKC ? 1 : 2) + (BKC ? 1 : 2)) / 2;
+      constexpr int kValuPer = EECT_PIPE_SCHED;
+      __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+#pragma unroll
+      for (int i = 0; i < kMfma; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, kValuPer, 0);
+        if (i & 1) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+        if (i == kMfma / 4) __builtin_amdgcn_sched_group_barrier(0x100, kReads, 0);
+      }
+    }
+#endif
 #ifdef EECT_TL
     if (kt < 4) EECT_STAMP(4 + 2 * kt), EECT_STAMP(5 + 2 * kt);
 #endif
@@ -415,9 +437,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
       if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
       split_store(ra0, rb0, 0);
       __syncthreads();
-      for (int kt = 0; kt < nk; kt += 2) {
-        pipe_step(kt, 0, ra1, rb1, ra0, rb0, fast_tag);
-        if (kt + 1 < nk) pipe_step(kt + 1, 1, ra0, rb0, ra1, rb1, fast_tag);
+      int kt = 0;
+      for (; kt + 3 < nk; kt += 2) {
+        pipe_step(kt, 0, ra1, rb1, ra0, rb0, fast_tag, FastTag<true>{});
+        pipe_step(kt + 1, 1, ra0, rb0, ra1, rb1, fast_tag, FastTag<true>{});
+      }
+      for (; kt < nk; kt += 2) {
+        pipe_step(kt, 0, ra1, rb1, ra0, rb0, fast_tag, FastTag<false>{});
+        if (kt + 1 < nk) pipe_step(kt + 1, 1, ra0, rb0, ra1, rb1, fast_tag, FastTag<false>{});
       }
     } else {
       if (nk > 1) load_ab(ra1, rb1, k_of(1), fast_tag);
@@ -627,16 +654,27 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
   constexpr int BM = 32 * TM * WGM, BN = 32 * TN * WGN;
   const dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.nz);
   const bool akc = g.a_k == 1, bkc = g.b_k == 1;
+#ifndef EECT_PIPE_MIN_K
+#define EECT_PIPE_MIN_K 0  // > 0: also build the pipelined loop and use it for contractions at least this long (EEC_TRAIN_PIPE_MIN_K overrides)
+#endif
 #ifndef EECT_STAGES
 #define EECT_STAGES 1  // measured on one box, default model: 1 -> 38.9 ms per step, 2 -> 40.6 ms, 2 for >= 32 k-tiles only -> 39.8 ms
 #endif
   const bool fancy = g.epi != EPI_NONE && g.epi != EPI_RELU;
   // bodies of their own: (epilogue, tile, layout) as the encoder's training plan launches them
   constexpr bool big = TM == 2 && TN == 2 && WGM == 2 && WGN == 2, wide = TM == 2 && TN == 1 && WGM == 2 && WGN == 2;
-#define EECT_GEMM_E(NP, AK, BK, E)                                                                              \
+  // the pipelined loop (STAGES 3: one barrier per k-tile, the split in the MFMAs' shadow, two workgroups per CU) is faster for long
+  // contractions ALONE (same-box A/B, bf16x3: K = 2048 87.6 -> 74.4 us, one workgroup per CU 330 -> 220 us; K = 256 75 -> 81 us) but
+  // buys nothing in the step, where the long GEMMs (weight gradients, side stream) share the chip with the dX chain: 25.2 vs 25.3 ms.
+  // Built only with -DEECT_PIPE_MIN_K=<K>.
+#if EECT_PIPE_MIN_K > 0
+  static const int pipe_min_k = [] { const char* e = getenv("EEC_TRAIN_PIPE_MIN_K"); return e ? atoi(e) : EECT_PIPE_MIN_K; }();  // tuning knob
+  const bool pipe = EECT_STAGES == 1 && g.K >= pipe_min_k;
+#endif
+#define EECT_GEMM_S(NP, AK, BK, E, ST)                                                                          \
   do {                                                                                                          \
-    auto kfn = gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, EECT_STAGES, E>;                                       \
-    constexpr int lds = gemm_lds_bytes<TM, TN, WGM, WGN, NP, EECT_STAGES>();                                    \
+    auto kfn = gemm_kernel<TM, TN, WGM, WGN, NP, AK, BK, ST, E>;                                                \
+    constexpr int lds = gemm_lds_bytes<TM, TN, WGM, WGN, NP, ST>();                                             \
     if (lds > 65536) {                                                                                          \
       static bool raised = false; /* per instantiation */                                                       \
       if (!raised) {                                                                                            \
@@ -646,6 +684,15 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
     }                                                                                                           \
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, g);                                                       \
   } while (0)
+#if EECT_PIPE_MIN_K > 0
+#define EECT_GEMM_E(NP, AK, BK, E)                     \
+  do {                                                 \
+    if (pipe) EECT_GEMM_S(NP, AK, BK, E, 3);           \
+    else EECT_GEMM_S(NP, AK, BK, E, EECT_STAGES);      \
+  } while (0)
+#else
+#define EECT_GEMM_E(NP, AK, BK, E) EECT_GEMM_S(NP, AK, BK, E, EECT_STAGES)
+#endif
   if constexpr (big || wide) {
     if (akc && bkc && g.epi == EPI_RESID) {
       if (np == 1) EECT_GEMM_E(1, true, true, EPI_RESID);
@@ -683,6 +730,7 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
   }
 #undef EECT_GEMM
 #undef EECT_GEMM_E
+#undef EECT_GEMM_S
   return hipGetLastError();
 }
 hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
