@@ -82,7 +82,9 @@ class _HipEncoderMixin:
 
     _head_attr = "linears"
     _pe_attr = "positional_encoder"
-    precision = "f16f8"  # fastest operand mode that meets the 1e-3 log-prob tolerance
+    # default operand mode: the one that keeps the north-star tolerance (|d log-prob| <= 1e-3, FLAT) on every committed fixture,
+    # the peaky (trained-like) one included.  "f16f8" is the faster opt-in: 1e-3 on near-uniform outputs only
+    precision = "f16x3"
     train_passes = 3     # training GEMMs: 3 = bf16 hi/lo split, three MFMA products (~fp32 results); 1 = plain bf16 operands
 
     def _hip_init(self, d_model, n_head, d_ff, dw_kernel, n_exits, n_layers, n_mels, vocab, max_len):
@@ -197,19 +199,30 @@ class _HipEncoderMixin:
         dev = next(self.parameters()).device
         named = [(n, p) for n, p in self.named_parameters()]
         self._dp = {"buckets": parallel.GradBuckets(named, self._cfg.n_exits, min_bucket_bytes=min_bucket_bytes),
-                    "weight": parallel.shard_weight(b_local, dev, group), "group": group, "deferred": [],
+                    "weight": parallel.shard_weight(b_local, dev, group), "group": group, "reduced": set(),
                     "active": parallel._active(group)}
 
     def sync_gradients(self) -> int:
-        """Join the gradient collectives the last backward started (or run them now if that backward could not use the
-        flat buckets: gradients accumulated into existing ``.grad`` tensors).  Returns the number of collectives joined."""
+        """Join the gradient collectives the last backward started from its progress callback and reduce EVERY other bucket
+        now: buckets whose gradients the backward could not write into the flat views (gradients accumulated into existing
+        ``.grad`` tensors, autograd-owned decoder gradients) and every bucket of a model whose backward does not report
+        into the buckets at all (Splitformer / Early_zipformer / the heads-only step: their autograd functions know nothing
+        of ``_dp``).  Call exactly once per backward, before clipping / the optimizer step.  Returns the number of
+        collectives joined."""
         dp = getattr(self, "_dp", None)
         if dp is None or not dp["active"]:
             return 0
-        for i in dp["deferred"]:
-            dp["buckets"].allreduce_bucket(i, dp["weight"], dp["group"])
-        dp["deferred"] = []
-        return dp["buckets"].wait()
+        buckets, early = dp["buckets"], dp["reduced"]
+        for i in range(len(buckets.buckets)):
+            if i not in early:
+                buckets.allreduce_bucket(i, dp["weight"], dp["group"])
+        n = buckets.wait()
+        # a bucket reduced from the callback was reduced BEFORE autograd installed its views as p.grad: if autograd kept a
+        # copy instead (a tensor hook, another live reference to the view), that copy was taken from an unreduced buffer
+        for i in early:
+            buckets.adopt_views(i)
+        dp["reduced"] = set()
+        return n
 
     # -- forward ------------------------------------------------------------
     def _workspace(self, B: int, T: int, device: torch.device) -> Tensor:
@@ -1109,13 +1122,14 @@ class _EncoderTrainFn(torch.autograd.Function):
                 # left to sync_gradients()
                 mine = set(names)
                 early = [use_views and all(n in mine for n, _ in b["params"]) for b in buckets.buckets]
-                dp["deferred"] = [i for i, ok in enumerate(early) if not ok]
+                dp["reduced"] = set()
 
                 def on_group(e, _user):
                     try:
                         for i in buckets.buckets_ready_after(e):
                             if early[i]:
                                 buckets.allreduce_bucket(i, weight, group, trusted=True)
+                                dp["reduced"].add(i)
                     except Exception as ex:  # never unwind through the C frames
                         err.append(ex)
                 if any(early):
@@ -1375,9 +1389,10 @@ class full_conformer(_HipEncoderMixin, nn.Module):
     def _decode_one(self, trg: Tensor, enc: Tensor, idx: int, log_softmax: bool = False, seed: Optional[int] = None) -> Tensor:
         if not trg.is_cuda:
             raise RuntimeError("the MI355X decoder runs on a HIP device only (there is no CPU fallback)")
-        if not (self.training and torch.is_grad_enabled()):
+        if not self.training:
             return self._hip_decoder(trg, enc, idx, log_softmax)  # inference: csrc/decoder.hip
-        # training with autograd (train.py:36-52): forward and backward on the HIP training kernels (csrc/decoder_train.hip)
+        # train mode (train.py:36-52), with or without autograd -- the reference's modules apply their dropout in train mode
+        # whatever the grad mode: forward (and backward) on the HIP training kernels (csrc/decoder_train.hip)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
         named = self._decoder_named_params(idx)
@@ -1497,12 +1512,10 @@ class full_conformer(_HipEncoderMixin, nn.Module):
 
     def forward(self, src: Tensor, lengths: Tensor, trg: Tensor):
         if self.training:
-            # train.py:36-52 (aed): encoder forward / backward on the HIP training kernels, the decoders (autograd through the
-            # reference's nn.TransformerDecoder on PyTorch-ROCm) consume the differentiable taps
+            # train.py:36-52 (aed): encoder AND decoders forward / backward on the HIP training kernels (eec_train_*,
+            # eec_decoder_train_*: _EncoderTrainFn, _DecoderTrainFn); the decoders consume the differentiable taps.  nn.TransformerDecoder
+            # only holds the parameters.  Without autograd the same train-mode forward runs (dropout in both halves) and the tape is dropped
             enc_out, taps = Early_conformer._forward_train(self, src, lengths, want_taps=True)
-            if not torch.is_grad_enabled():
-                dec_out = torch.stack([self._decode_one(trg, taps[e], e) for e in range(self._cfg.n_exits)])
-                return dec_out, enc_out
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())  # one seed per forward: the exits share the embedding's dropout mask
             dec_out = torch.stack([self._decode_one(trg, taps[e], e, seed=seed) for e in range(self._cfg.n_exits)])
             return dec_out, enc_out

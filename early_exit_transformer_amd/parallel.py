@@ -44,8 +44,6 @@ def _active(group) -> bool:
 # (device, b_local) -> device-resident [b_local] fp32: built once, so a step never pays a blocking pageable host -> device
 # copy (the stall eec_upload_i64 removed for `lengths`)
 _count_cache: Dict[Tuple[torch.device, int], torch.Tensor] = {}
-# (group id, b_local) -> this rank's weight b_local / sum_r b_r as a python float (one exchange per shard size, not per step)
-_weight_cache: Dict[Tuple[int, int], float] = {}
 
 
 def _count_tensor(b_local: int, device: torch.device) -> torch.Tensor:
@@ -58,18 +56,25 @@ def _count_tensor(b_local: int, device: torch.device) -> torch.Tensor:
 
 
 def shard_weight(b_local: int, device: torch.device, group: Optional[dist.ProcessGroup] = None) -> float:
-    """b_local / (global batch): this rank's weight in a batch mean.  The shard sizes are exchanged ONCE per (group, b_local)
-    and cached (every rank must call it with its own size at the same point, as for any collective)."""
+    """b_local / (global batch): this rank's weight in a batch mean, as a python float.  SET-UP TIME ONLY
+    (``enable_data_parallel``, where the shard size is fixed by contract): one all-reduce and one read-back on EVERY call --
+    never cached, so every rank that calls it issues the collective (a cache keyed on this rank's size alone would let a rank
+    whose size did not change skip a collective its peers enter).  The per-step path uses ``shard_weight_tensor``."""
     if not _active(group):
         return 1.0
-    key = (id(group) if group is not None else 0, int(b_local))
-    w = _weight_cache.get(key)
-    if w is None:
-        total = _count_tensor(b_local, device).clone()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
-        w = float(b_local) / float(total.item())  # set-up time only
-        _weight_cache[key] = w
-    return w
+    return float(shard_weight_tensor(b_local, device, group).item())
+
+
+def shard_weight_tensor(b_local: int, device: torch.device, group: Optional[dist.ProcessGroup] = None) -> torch.Tensor:
+    """The same weight as a device-resident [1] fp32 tensor: ONE all-reduce of one float, issued unconditionally by every
+    rank on every call, no host read-back -- safe on a per-step path whose shard sizes change between steps (a last partial
+    batch)."""
+    cnt = _count_tensor(b_local, device)
+    if not _active(group):
+        return torch.ones_like(cnt)
+    total = cnt.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    return cnt / total
 
 
 def combine_exit_losses(local_mean: torch.Tensor, b_local: int, group: Optional[dist.ProcessGroup] = None,
@@ -214,6 +219,21 @@ class GradBuckets:
         self._pending = []
         return n
 
+    def adopt_views(self, i: int) -> int:
+        """After ``wait()``: make sure every ``p.grad`` of bucket ``i`` holds the REDUCED values of its view.  A bucket reduced
+        from the backward's callback was reduced before autograd installed the views; if autograd installed a copy instead (a
+        tensor hook, another live reference), that copy is stale: overwrite it.  Returns the number of gradients repaired."""
+        b, fixed = self.buckets[i], 0
+        base = b["flat"].data_ptr()
+        for n, p in b["params"]:
+            if p.grad is None:
+                continue
+            _, off, cnt = self._where[n]
+            if p.grad.data_ptr() != base + 4 * off:
+                p.grad.copy_(b["flat"][off:off + cnt].view_as(p.grad))
+                fixed += 1
+        return fixed
+
     def allreduce_all(self, weight: float, group: Optional[dist.ProcessGroup] = None) -> int:
         """Every bucket, in completion order, then ``wait()``: the form for a backward that did not report its progress."""
         for i in range(len(self.buckets)):
@@ -226,15 +246,16 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], b_local: int, buck
     """Stand-alone form for gradients that are ordinary tensors (any module, no flat buckets): after the local backward,
     average ``p.grad`` over the ranks, weighted by the ranks' utterance counts.  Gradients are flattened into buckets of
     ``bucket_bytes`` in reverse parameter order (the order the backward produced them), each bucket ONE all-reduce, all of
-    them in flight together.  The shard weight comes from ``shard_weight`` (one exchange per shard size, cached): no
-    per-step host read-back.  Returns the number of gradient collectives.  BatchNorm statistics stay per replica.
+    them in flight together.  The shard weight is exchanged on EVERY call (``shard_weight_tensor``: one float, every rank
+    always enters the collective, so shard sizes may change from step to step) and stays on the device: no per-step host
+    read-back.  Returns the number of gradient collectives.  BatchNorm statistics stay per replica.
     Models that train through ``eec_train_backward`` use ``GradBuckets`` instead (in-place buffers, overlapped)."""
     if not _active(group):
         return 0
     with_grad = [p for p in params if p.grad is not None]
     if not with_grad:
         return 0
-    w = shard_weight(b_local, with_grad[0].grad.device, group)
+    w = shard_weight_tensor(b_local, with_grad[0].grad.device, group)
     pending, bucket, size = [], [], 0
 
     def flush():

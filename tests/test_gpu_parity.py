@@ -2,10 +2,13 @@
 nn.Module -> ctypes -> C-ABI, against the CPU oracle and the committed golden fixtures.
 
 Tolerances (max |delta log-prob| vs the fp32 reference path, stated per operand mode):
-    f16f8  1e-3   (default: as f16x3 with the correction products of every GEMM but the heads in block-scaled fp8; measured 4.1e-4)
-    f16x3  1e-3   (north_star's tolerance, FLAT on every fixture incl. the peaky one; measured 3.8e-5 on the 12-layer model, 3.7e-4 peaky)
-    mixed  2.5e-3 (measured 1.0-1.3e-3)
-    f16    6e-3   (measured 3.0e-3)
+    f16x3  1e-3   DEFAULT.  The north_star's tolerance, FLAT, on every fixture incl. the peaky (trained-like) one; measured 3.8e-5 on the
+                  12-layer model, 3.7e-4 peaky.  Every test that does not name a mode runs this one.
+    f16f8  1e-3 x max(1, max|logp| / 8)   opt-in fast mode (correction products of every GEMM but the heads in block-scaled fp8):
+                  1e-3 flat on near-uniform outputs (measured 4.1e-4), NOT on peaky ones (4.1e-3 at max|logp| 59) -- it does not
+                  claim the north-star tolerance there and is not the default
+    mixed  2.5e-3 x the same factor (measured 1.0-1.3e-3)
+    f16    6e-3   x the same factor (measured 3.0e-3)
 """
 import numpy as np
 import pytest
@@ -19,6 +22,8 @@ from oracle import conformer_ref as R
 
 pytestmark = pytest.mark.gpu
 TOL = {"f16f8": 1e-3, "f16x3": 1e-3, "mixed": 2.5e-3, "f16": 6e-3}
+FLAT_MODES = ("f16x3",)  # modes that claim the north-star tolerance as a FLAT bound on every output, peaky ones included
+DEFAULT_MODE = "f16x3"
 
 
 def make_pair(kw, seed, style="trained", head_scale=1.0):
@@ -30,7 +35,7 @@ def make_pair(kw, seed, style="trained", head_scale=1.0):
     return ref, gpu.cuda()
 
 
-def run_gpu(model, mel, lens, prec="f16f8"):
+def run_gpu(model, mel, lens, prec=DEFAULT_MODE):
     model.precision = prec
     with torch.no_grad():
         out = model(mel.cuda(), lens)
@@ -46,10 +51,13 @@ def test_native_library_is_loaded():
 
 
 def logp_tolerance(prec, want_logp):
-    """Tolerance policy (README / INTEGRATION.md): |dlogp| <= TOL[prec] * max(1, max|logp| / LOGP_UNIT).  The operand
-    rounding of a mode is a RELATIVE error on the logits, so the absolute log-prob error grows with the logit scale;
-    near-uniform outputs (|logp| <= ~8: random-init heads, log 256 = 5.5) get the flat north-star tolerance, peaky ones
-    (trained / x8 heads: |logp| up to 40) the same bound relative to their scale."""
+    """The default mode (FLAT_MODES): the north-star tolerance, flat -- |dlogp| <= 1e-3 whatever the outputs look like.
+    The opt-in faster modes state a weaker bound: |dlogp| <= TOL[prec] * max(1, max|logp| / LOGP_UNIT) -- their operand
+    rounding is a RELATIVE error on the logits, so the absolute log-prob error grows with the logit scale; near-uniform
+    outputs (|logp| <= ~8: random-init heads, log 256 = 5.5) get the flat bound, peaky ones the same bound relative to
+    their scale (README / INTEGRATION.md say so where they describe the modes)."""
+    if prec in FLAT_MODES:
+        return TOL[prec]
     return TOL[prec] * max(1.0, float(np.abs(want_logp).max()) / LOGP_UNIT)
 
 
@@ -79,12 +87,12 @@ def test_golden_logprobs(name, prec):
     print(f"\n[parity] {name:14s} {prec:6s} max|dlogp| {err:.3e}  on logp >= -10: {err_top:.3e}  max|logp| {scale:6.2f}  "
           f"err/scale {err / scale:.2e}  tolerance {logp_tolerance(prec, z['logp']):.2e}")
     assert err_top <= err
+    # the mode's stated bound: FLAT 1e-3 on every fixture for the default mode (no exemption: the peaky, trained-like fixture
+    # included -- Q, K and the attention probabilities keep fp16 residuals; measured 3.7e-4 at max|logp| 59); the opt-in modes'
+    # own bound otherwise, which is flat as well wherever max|logp| <= 8
     assert err < logp_tolerance(prec, z["logp"]), f"{name}/{prec}: max|dlogp| {err:.3e} at max|logp| {scale:.1f}"
-    # the flat north-star tolerance (1e-3, no scaling) holds outright on every near-uniform fixture in every mode's own flat bound,
-    # and in the exact parity mode f16x3 ALSO on the peaky (heads x 8, trained-like) fixture: Q, K and the attention probabilities
-    # keep fp16 residuals there (round 3; measured 3.7e-4 at max|logp| 59)
-    if name != "config1_peaky" or prec == "f16x3":
-        assert err < TOL[prec], f"{name}/{prec}: the FLAT tolerance: max|dlogp| {err:.3e}"
+    if prec in FLAT_MODES:
+        assert err < 1e-3, f"{name}/{prec}: the north-star tolerance: max|dlogp| {err:.3e}"
     # a checksum of checksums over the FULL tensor (fixtures keep every stride-th frame only).  A logit error on a row's
     # dominant class shifts the whole row's log-probs together, so the errors of a row do not average out: the bound is
     # a quarter of "every element off by the tolerance"
@@ -93,22 +101,25 @@ def test_golden_logprobs(name, prec):
 
 
 def test_golden_greedy_decode_exact():
-    """Greedy CTC (util/beam_infer.py:9-24) on peaky heads: token sequences identical to the reference's for
-    every (exit, utterance) whose frames all have a top-2 margin above twice the log-prob tolerance."""
+    """Greedy CTC (util/beam_infer.py:9-24) on peaky heads, in the DEFAULT mode: token sequences identical to the reference's
+    for every (exit, utterance) whose frames all have a top-2 margin above twice the bound that mode is held to on this very
+    fixture (test_golden_logprobs: flat 1e-3, measured 3.7e-4) -- two log-probs off by less than the bound each cannot swap."""
     z, kw = load_golden("config1_peaky")
     gpu = Early_conformer(**{**kw, "device": "cuda"}).eval()
     gpu.load_state_dict(synth.synth_state_dict(gpu.state_dict(), seed=int(z["seed"]), style=str(z["style"]),
                                                head_scale=float(z["head_scale"])))
     gpu = gpu.cuda()
     mel = synth.synth_mel(int(z["B"]), 80, int(z["T"]), seed=int(z["seed"]))
-    gpu.precision = "f16f8"
+    assert gpu.precision == DEFAULT_MODE  # the class default: nothing selects a mode here
+    bound = logp_tolerance(gpu.precision, z["logp"])
     with torch.no_grad():
         out = gpu(mel.cuda(), torch.from_numpy(z["lengths"]))
         got = gpu.greedy_decode(out)
+    assert np.abs(out[:, :, ::int(z["stride"])].cpu().numpy() - z["logp"]).max() < bound  # the bound the margin filter relies on
     E, B = z["greedy_counts"].shape
     flat, pos, compared = z["greedy_flat"].tolist(), 0, 0
-    safe = (z["margin"] > 2 * TOL["f16x3"]).all(axis=-1)  # [E,B]
-    frame_ok = z["margin"] > 2 * TOL["f16x3"]
+    safe = (z["margin"] > 2 * bound).all(axis=-1)  # [E,B]
+    frame_ok = z["margin"] > 2 * bound
     am = out.argmax(-1).cpu().numpy()
     assert (am[frame_ok] == z["argmax"][frame_ok]).all(), "argmax differs on a frame with a safe margin"
     for e in range(E):
@@ -207,7 +218,7 @@ def test_ragged_shapes(B, T, lens):
         want = ref(mel, lt)
     got = run_gpu(gpu, mel, lt)
     assert got.shape == want.shape
-    assert (got - want).abs().max().item() < TOL["f16f8"]
+    assert (got - want).abs().max().item() < TOL[DEFAULT_MODE]
     assert torch.allclose(got.exp().sum(-1), torch.ones(got.shape[:-1]), atol=1e-4)
 
 
@@ -225,7 +236,7 @@ def test_config_surface(over):
     assert (run_gpu(gpu, mel, lens) - want).abs().max().item() < TOL["f16x3"]
 
 
-@pytest.mark.parametrize("case", range(10))
+@pytest.mark.parametrize("case", range(40))
 def test_random_configs_and_batches(case):
     """Seeded random sweep over the supported configuration surface and ragged batches (the reference's own tests
     hold no such cases; the oracle is the judge)."""
@@ -242,7 +253,7 @@ def test_random_configs_and_batches(case):
     mel, lt = synth.synth_mel(B, kw["features_length"], T, seed=case), torch.tensor(lens)
     with torch.no_grad():
         want = ref(mel, lt)
-    prec = ["f16f8", "f16x3"][case % 2]
+    prec = "f16f8" if case % 4 == 3 else DEFAULT_MODE  # three quarters of the sweep in the default mode
     got = run_gpu(gpu, mel, lt, prec)
     assert got.shape == want.shape
     assert (got - want).abs().max().item() < TOL[prec], (kw, B, T, lens.tolist())
@@ -429,7 +440,7 @@ def test_long_utterances_two_key_chunks_default_model():
     idx = [0, 4]
     with torch.no_grad():
         want = ref(mel[idx], lens[idx])
-    assert (out[:, idx] - want).abs().max().item() < TOL["f16f8"]
+    assert (out[:, idx] - want).abs().max().item() < TOL[DEFAULT_MODE]
 
 
 @pytest.mark.parametrize("prec", ["f16f8", "f16x3"])
@@ -992,7 +1003,7 @@ class TestConfig3FullSize:
         idx = [0, 17, 63]
         with torch.no_grad():
             want = ref(mel[idx], lens[idx])
-        assert (out[:, idx] - want).abs().max().item() < TOL["f16f8"]
+        assert (out[:, idx] - want).abs().max().item() < TOL[DEFAULT_MODE]
         got3 = run_gpu(gpu, mel, lens, "f16x3")
         assert (got3[:, idx] - want).abs().max().item() < TOL["f16x3"]
 
@@ -1081,7 +1092,7 @@ def test_exit_heads_trainable_on_frozen_encoder():
             lr.bias.copy_(lg.bias.cpu())
     gpu.eval()
     with torch.no_grad():
-        assert (gpu(mel.cuda(), lens).cpu() - ref(mel, lens)).abs().max().item() < TOL["f16f8"]
+        assert (gpu(mel.cuda(), lens).cpu() - ref(mel, lens)).abs().max().item() < TOL[DEFAULT_MODE]
     # a trainable encoder parameter selects the full training step (tests/test_gpu_train.py)
     gpu.train()
     gpu.conformer[0].conformer_layers[0].ffn1.sequential[1].weight.requires_grad_(True)
@@ -1124,7 +1135,7 @@ def test_mel_frontend_against_oracle():
     mel_len = 1 + lens // 160
     with torch.no_grad():
         w2 = ref(want, mel_len)
-    assert (run_gpu(gpu, got, mel_len) - w2).abs().max().item() < TOL["f16f8"]
+    assert (run_gpu(gpu, got, mel_len) - w2).abs().max().item() < TOL[DEFAULT_MODE]
 
 
 @pytest.mark.parametrize("N,T,V,beam,scale", [(4, 40, 16, 10, 3.0), (6, 256, 256, 10, 4.0), (3, 97, 64, 4, 2.0), (2, 300, 256, 16, 6.0),

@@ -205,12 +205,23 @@ def _grad_rank_main(rank, world, port, q):
         lo, hi = parallel.shard_range(B, rank, world)
         R.summed_exit_ctc_loss(m(mel[lo:hi], lens[lo:hi]), tgt[lo:hi], tl[lo:hi]).backward()
         n_coll = parallel.allreduce_gradients(list(m.parameters()), hi - lo, bucket_bytes=100 << 10)
+        got = [p.grad.clone() for p in m.parameters()]
+        # a LAST PARTIAL BATCH: 3 + 2 utterances above, 2 + 2 now -- rank 1's own size is unchanged, rank 0's is not.  Every rank
+        # must still enter the same collectives (a weight cached per rank-local size would let rank 1 skip the exchange) and
+        # the weights must follow the new sizes
+        m.zero_grad()
+        lo2, hi2 = (0, 2) if rank == 0 else (2, 4)
+        R.summed_exit_ctc_loss(m(mel[lo2:hi2], lens[lo2:hi2]), tgt[lo2:hi2], tl[lo2:hi2]).backward()
+        parallel.allreduce_gradients(list(m.parameters()), hi2 - lo2, bucket_bytes=100 << 10)
+        got2 = [p.grad.clone() for p in m.parameters()]
         if rank == 0:
-            got = [p.grad.clone() for p in m.parameters()]
+            rel = lambda got: max(((g - p.grad).abs().max() / (p.grad.abs().max() + 1e-6)).item() for g, p in zip(got, m.parameters()))  # noqa: E731
             m.zero_grad()
             R.summed_exit_ctc_loss(m(mel, lens), tgt, tl).backward()
-            err = max(((g - p.grad).abs().max() / (p.grad.abs().max() + 1e-6)).item() for g, p in zip(got, m.parameters()))
-            q.put((n_coll, err))
+            err = rel(got)
+            m.zero_grad()
+            R.summed_exit_ctc_loss(m(mel[:4], lens[:4]), tgt[:4], tl[:4]).backward()
+            q.put((n_coll, max(err, rel(got2))))
     finally:
         dist.destroy_process_group()
 
@@ -226,7 +237,7 @@ def test_world2_gloo_bucketed_gradient_allreduce_equals_global_batch_gradient():
     n_coll, err = q.get(timeout=180)
     [p.join(60) for p in procs]
     assert all(p.exitcode == 0 for p in procs)
-    assert n_coll >= 2  # more than one bucket (the shard sizes are exchanged once and cached, not per step)
+    assert n_coll >= 2  # more than one bucket (the shard-size exchange is a collective of its own, on every call)
     assert err < 1e-4
 
 
@@ -247,7 +258,9 @@ def _bucket_rank_main(rank, world, port, q):
         gb = parallel.GradBuckets(named, n_groups=2, min_bucket_bytes=0)
         order = [b["ready_after"] for b in gb.buckets]
         w = parallel.shard_weight(hi - lo, torch.device("cpu"))
-        assert parallel.shard_weight(hi - lo, torch.device("cpu")) == w  # cached: no second exchange
+        assert w == pytest.approx((hi - lo) / 6.0)
+        # never cached: a second call is a second exchange every rank enters (same answer)
+        assert parallel.shard_weight(hi - lo, torch.device("cpu")) == w
 
         def local_backward():
             m.zero_grad(set_to_none=True)
@@ -298,6 +311,71 @@ def test_world2_gloo_flat_gradient_buckets_reduce_in_place_per_exit_group():
     assert eq == pytest.approx([1.5, 2.5])
 
 
+def _sync_rank_main(rank, world, port, q):
+    """sync_gradients() of a model whose backward never reports into the buckets (Splitformer / Early_zipformer / the heads-only
+    step go through autograd functions that know nothing of _dp): every bucket must still be reduced."""
+    import types
+    from early_exit_transformer_amd.model import _HipEncoderMixin
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class Toy(_HipEncoderMixin, torch.nn.Module):  # the mixin's data-parallel half needs only _cfg.n_exits and parameters
+            def __init__(self):
+                torch.nn.Module.__init__(self)
+                self.conformer = torch.nn.ModuleList([torch.nn.Linear(8, 8) for _ in range(2)])
+                self.linears = torch.nn.ModuleList([torch.nn.Linear(8, 4) for _ in range(2)])
+                self.stem = torch.nn.Linear(3, 8)
+                self._cfg = types.SimpleNamespace(n_exits=2)
+                self._enc = self._trainer = None
+        torch.manual_seed(0)
+        m = Toy()
+        b_local = 3 if rank == 0 else 1
+        m.enable_data_parallel(b_local, min_bucket_bytes=0)
+        # (1) plain autograd gradients, nothing reduced from a callback
+        for i, p in enumerate(m.parameters()):
+            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+        n1 = m.sync_gradients()
+        want = [(3 * 1 + 1 * 2) / 4.0 * (i + 1) for i in range(len(list(m.parameters())))]
+        ok1 = all(torch.allclose(p.grad, torch.full_like(p, w)) for p, w in zip(m.parameters(), want))
+        # (2) a bucket reduced from the backward's callback whose views autograd did NOT adopt (a hook made it clone): p.grad is
+        # a stale copy taken before the reduction -> sync_gradients() repairs it from the reduced view
+        dp = m._dp
+        gb = dp["buckets"]
+        named = dict(m.named_parameters())
+        for p in m.parameters():
+            p.grad = None
+        i0 = 0
+        for n, p in gb.buckets[i0]["params"]:
+            gb.view(n, p).fill_(float(rank + 1))
+        gb.allreduce_bucket(i0, dp["weight"], dp["group"], trusted=True)
+        dp["reduced"] = {i0}
+        for n, p in gb.buckets[i0]["params"]:
+            p.grad = torch.full_like(p, float(rank + 1))  # the unreduced copy
+        for i in range(1, len(gb.buckets)):
+            for n, p in gb.buckets[i]["params"]:
+                p.grad = torch.full_like(p, float(rank + 1))
+        n2 = m.sync_gradients()
+        ok2 = all(torch.allclose(p.grad, torch.full_like(p, (3 * 1 + 1 * 2) / 4.0)) for p in m.parameters())
+        if rank == 0:
+            q.put((n1, ok1, n2, ok2, len(gb.buckets), dp["reduced"] == set()))
+        assert named
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_gloo_sync_gradients_reduces_buckets_the_backward_never_reported():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sync_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    n1, ok1, n2, ok2, nb, cleared = q.get(timeout=120)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    assert nb == 3 and n1 == nb and ok1
+    assert n2 == nb and ok2 and cleared
+
+
 def _run_bench(extra_env, *argv):
     import subprocess
     import sys
@@ -335,7 +413,10 @@ def test_bench_rank_failing_inside_a_step_fails_the_job():
     res = _run_bench({"EEC_BENCH_FAIL_STEP_RANK": "1", "EEC_BENCH_TRAIN_TIMEOUT": "60"}, "--gpus", "2", "--steps", "1")
     assert res.returncode == 4, (res.returncode, res.stderr)
     assert "rank 1 exited with status 4" in res.stderr
-    assert len([ln for ln in res.stdout.splitlines() if ln.startswith("{")]) <= 1
+    # rank 0 was blocked in a collective when the launcher terminated it: its SIGTERM thread still emits the ONE record
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    assert "peer rank failed" in json.loads(lines[0])["train_step"]["error"]
     res = _run_bench({"EEC_BENCH_FAIL_STEP_RANK": "0", "EEC_BENCH_TRAIN_TIMEOUT": "60"}, "--gpus", "2", "--steps", "1")
     assert res.returncode == 4, (res.returncode, res.stderr)
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
