@@ -225,7 +225,11 @@ __device__ __forceinline__ void ring_fill(WRing<NP, PF, NT>& r, const uint4* __r
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         r.q[p][nt][0] = w_lane[nt * nt_stride + (size_t)p * 128];
+#ifdef EEC_X3_LO_SKIP  // timing-only build: the lo fragments are not loaded (what a 2 B / weight stream would cost)
+        if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = r.q[p][nt][0];
+#else
         if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = w_lane[nt * nt_stride + (size_t)p * 128 + 64];
+#endif
       }
     }
   __builtin_amdgcn_sched_barrier(0);  // keep these loads HERE: one stage ahead of their consumer
@@ -298,7 +302,11 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_l
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         r.q[s % PF][nt][0] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128];
+#ifdef EEC_X3_LO_SKIP
+        if (NP == 3) r.q[s % PF][nt][LO] = r.q[s % PF][nt][0];
+#else
         if (NP == 3) r.q[s % PF][nt][LO] = w_lane[nt * nt_stride + (size_t)(s + PF) * 128 + 64];
+#endif
       }
     }
     side(s);
