@@ -182,7 +182,21 @@ __device__ __forceinline__ float silu_exp2(float u) {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x)); }
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+#ifdef EEC_MFMA_SHAPE_TIMING
+  // timing-only build (WRONG results): the same MACs as two v_mfma_f32_16x16x32_f16 on two quarters of the accumulator -- what the
+  // chip's clock does with the other fp16 MFMA shape inside the real kernels (tools/mfma_shape_bench.hip: 16x16x32 holds ~2.05 GHz
+  // where 32x32x16 holds ~1.7 GHz in bare loops on random data)
+  static_assert(true, "");
+  f32x4 q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+  f32x4 q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
+  q2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q2, 0, 0, 0);
+  const f32x16 lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7);
+  const f32x16 hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 // row of accumulator register i for this lane (within a 32x32 tile)
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
