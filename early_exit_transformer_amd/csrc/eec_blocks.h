@@ -36,6 +36,33 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[MT][NT], const float
     }
 }
 
+// The same start values in the layout the format's k-loop wants: the quadrant layout for the split format on the 16x16x32 shape
+// (eec_device.h, EEC_MFMA16: register 4 (2 ra + cb) + j <-> output feature 16 ra + 8 hh + 4 u + j, both frame blocks cb), so that
+// the product needs no conversion on the way in; the standard layout otherwise.
+template <int NP, int MT, int NT>
+__device__ __forceinline__ void acc_init_bias_np(f32x16 (&acc)[MT][NT], const float* __restrict__ bias_n0, float scale = 1.0f) {
+  if constexpr (kMfma16For<NP>) {
+    const int lane = lane_id(), hh = lane >> 5, u = (lane >> 4) & 1;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int ra = 0; ra < 2; ++ra) {
+        const float4 bb = *(const float4*)(bias_n0 + 32 * nt + 16 * ra + 8 * hh + 4 * u);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) {
+            acc[mt][nt][4 * (2 * ra + cb) + 0] = bb.x * scale;
+            acc[mt][nt][4 * (2 * ra + cb) + 1] = bb.y * scale;
+            acc[mt][nt][4 * (2 * ra + cb) + 2] = bb.z * scale;
+            acc[mt][nt][4 * (2 * ra + cb) + 3] = bb.w * scale;
+          }
+      }
+  } else {
+    acc_init_bias<MT, NT>(acc, bias_n0, scale);
+  }
+}
+
 // first fragment (this lane) of n-tile nt of a packed [N][16 KS] matrix
 template <int KS>
 __device__ __forceinline__ const uint4* wfrag_lane(const uint4* wp, int nt) {
@@ -84,7 +111,8 @@ __device__ __forceinline__ void proj_gemm(f32x16 (&acc)[MT][NT], const char* sme
     gemm_ring_f8<NG, NT, true, PF, NoSide, 0, kProjNWB, 0, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(acc, a_lane, G::kALd, a8_lane, G::kA8Ld, rec,
                                                                                                     (size_t)NG * kF8Rec, st.r, st.wg);
   } else {
-    gemm_ring<NP, KS, NT, true, PF, NoSide, 0, MT>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(w.wp, t0), (size_t)KS * 128, st.r);
+    // (the accumulators come from acc_init_bias_np: already in the layout this format's k-loop wants)
+    gemm_ring<NP, KS, NT, true, PF, NoSide, 0, MT, !kMfma16For<NP>, true>(acc, a_lane, G::kALd, G::kAPlane, wfrag_lane<KS>(w.wp, t0), (size_t)KS * 128, st.r);
   }
   (void)row_stride_mul;
 }
@@ -124,7 +152,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
   f32x16 acc[MT][NW];
   // ---- Q ----
   proj_fill<D, NP, kLPF, NW>(rk, wm, TQ + t0);
-  acc_init_bias<MT, NW>(acc, a.bias + 32 * t0);
+  acc_init_bias_np<NP, MT, NW>(acc, a.bias + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, t0);
   proj_fill<D, NP, kLPF, NW>(rq, wm, 2 * TQ + t0);  // V weights, in flight during the K pass
   {
@@ -152,7 +180,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
       }
   }
   // ---- K ----
-  acc_init_bias<MT, NW>(acc, a.bias + D + 32 * t0);
+  acc_init_bias_np<NP, MT, NW>(acc, a.bias + D + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rk, wm, TQ + t0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -176,7 +204,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
       }
     }
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
-  acc_init_bias<MT, NW>(acc, a.bias + 2 * D + 32 * t0);
+  acc_init_bias_np<NP, MT, NW>(acc, a.bias + 2 * D + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, 2 * TQ + t0);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -389,7 +417,7 @@ __device__ __forceinline__ void pw2_gemm(f32x16 (&acc2)[Geo<D>::kMT][Geo<D>::kNW
                                          ProjStream<NP, kDPF, Geo<D>::kNW>& r) {
   using G = Geo<D>;
   const int w = wave_id();
-  acc_init_bias<G::kMT, G::kNW>(acc2, a.bias + 32 * G::kNW * w);
+  acc_init_bias_np<NP, G::kMT, G::kNW>(acc2, a.bias + 32 * G::kNW * w);
   proj_gemm<D, NP, kDPF, G::kNW, G::kMT>(acc2, smem, r, WMat{a.wp, a.wf8}, G::kNW * w);
 }
 

@@ -182,21 +182,7 @@ __device__ __forceinline__ float silu_exp2(float u) {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x)); }
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
-#ifdef EEC_MFMA_SHAPE_TIMING
-  // timing-only build (WRONG results): the same MACs as two v_mfma_f32_16x16x32_f16 on two quarters of the accumulator -- what the
-  // chip's clock does with the other fp16 MFMA shape inside the real kernels (tools/mfma_shape_bench.hip: 16x16x32 holds ~2.05 GHz
-  // where 32x32x16 holds ~1.7 GHz in bare loops on random data)
-  static_assert(true, "");
-  f32x4 q0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), q1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
-  f32x4 q2 = __builtin_shufflevector(c, c, 8, 9, 10, 11), q3 = __builtin_shufflevector(c, c, 12, 13, 14, 15);
-  q0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q0, 0, 0, 0);
-  q2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, q2, 0, 0, 0);
-  const f32x16 lo = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7);
-  const f32x16 hi = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7, 0, 1, 2, 3, 4, 5, 6, 7);
-  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 16, 17, 18, 19, 20, 21, 22, 23);
-#else
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-#endif
 }
 // row of accumulator register i for this lane (within a 32x32 tile)
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
@@ -228,7 +214,7 @@ struct WRing {
 };
 
 template <int NP, int PF, int NT>
-__device__ __forceinline__ void ring_fill(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride,
+__device__ __forceinline__ void ring_fill_32(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride,
                                           int steps_avail) {
 #ifdef EEC_ABLATE_W
   if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
@@ -262,9 +248,9 @@ struct NoSide {
 // work's dependent VALU chain is spread over the MFMA issue gaps (an in-order wave otherwise runs it
 // as one serial chain after the MFMAs, ~150-250 exposed cycles per step).
 template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int MT = 2>
-__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
-                                          const uint4* __restrict__ w_lane, size_t nt_stride,
-                                          WRing<NP, PF, NT>& r, Side side = Side()) {
+__device__ __forceinline__ void gemm_ring_32(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                             const uint4* __restrict__ w_lane, size_t nt_stride,
+                                             WRing<NP, PF, NT>& r, Side side = Side()) {
   constexpr int LO = (NP == 3) ? 1 : 0;
   h8 ah[2][MT], al[2][MT];  // [buffer][mt]
 #pragma unroll
@@ -340,7 +326,7 @@ __device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_l
 
 // Same product with a runtime k-step count and no ring (ragged tails only).
 template <int NP, int NT, bool SWAP, int MT = 2>
-__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+__device__ __forceinline__ void gemm_plain_32(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
                                            const uint4* __restrict__ w_lane, size_t nt_stride, int ks) {
   for (int s = 0; s < ks; ++s) {
 #pragma unroll
@@ -400,6 +386,266 @@ __device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][NT], const char
       }
     }
   }
+}
+
+// ===========================================================================
+// The same products on v_mfma_f32_16x16x32_f16 (EEC_MFMA16, the default).  The two fp16 shapes have the same MACs per cycle, but
+// under load the chip holds a higher clock on 16x16x32 (tools/mfma_shape_bench.hip: 2.02-2.08 GHz against 1.69-1.74 GHz in bare
+// loops on random data; timing-only swap inside these kernels: chain launch -7.7 %, profiles/r04_micro_mfma_shape_clock.txt).
+// Everything around the k-loops keeps its layouts; only the lane <-> element map of the loads and of the accumulators differs:
+//   * lane l = 32 hh + 16 u + c.  An operand fragment of row block rb (16 rows) and DOUBLE k-step S (32 k) holds, in lane l,
+//     row 16 rb + c, k = 32 S + 8 (2 hh + u) + j.  From an LDS plane that is just another address; in the packed weights (1-KiB
+//     fragments per 16-deep k-step, lane-linear) it is fragment 2 S + hh, slot 16 rb + c + 32 u -- another per-lane pointer into
+//     the SAME packing.  A ring entry p is (S = p / 2, rb = p % 2): the ring holds the same bytes as before, differently dealt.
+//   * a 32 x 32 accumulator tile is four 16 x 16 quadrants (ra, cb) in registers 4 (2 ra + cb) + i: m = 16 ra + 4 (2 hh + u) + i,
+//     n = 16 cb + c ("quadrant layout").  The standard layout every epilogue expects (n = 16 u + c, m = (i & 3) + 8 (i >> 2) + 4 hh)
+//     is restored with v_permlane16_swap + v_permlane32_swap on the register pairs (4 (2 ra) + i, 4 (2 ra + 1) + i): 32 cross-lane
+//     instructions per tile, once per accumulation (acc_q_to_std / acc_std_to_q).
+// ===========================================================================
+#ifndef EEC_MFMA16
+#define EEC_MFMA16 1
+#endif
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+// quadrant (ra, cb) of a tile += A[ra] . B[cb]^T for ra, cb in {0, 1}
+__device__ __forceinline__ void tile_mac16(f32x16& acc, const h8 (&a)[2], const h8 (&b)[2]) {
+#pragma unroll
+  for (int ra = 0; ra < 2; ++ra)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int q = 4 * (2 * ra + cb);
+      f32x4 t = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
+      t = mfma32(a[ra], b[cb], t);
+      acc[q] = t[0], acc[q + 1] = t[1], acc[q + 2] = t[2], acc[q + 3] = t[3];
+    }
+}
+// The lane exchanges of one tile as ONE block of in-place asm (both registers of a swap are read and written; a chain of the
+// builtins loses its second result in hipcc 7.2).  The eight pairs are independent, so inside the block no swap reads a register
+// written fewer than seven instructions earlier; the leading s_nop covers a VALU write right in front of the block.
+#define EEC_SWAP8(OP)                                                                                                        \
+  "v_permlane" OP "_swap_b32 %0, %4\n\tv_permlane" OP "_swap_b32 %1, %5\n\tv_permlane" OP "_swap_b32 %2, %6\n\t"            \
+  "v_permlane" OP "_swap_b32 %3, %7\n\tv_permlane" OP "_swap_b32 %8, %12\n\tv_permlane" OP "_swap_b32 %9, %13\n\t"          \
+  "v_permlane" OP "_swap_b32 %10, %14\n\tv_permlane" OP "_swap_b32 %11, %15\n\t"
+__device__ __forceinline__ void acc_q_to_std(f32x16& acc) {
+  float r0 = acc[0], r1 = acc[1], r2 = acc[2], r3 = acc[3], r4 = acc[4], r5 = acc[5], r6 = acc[6], r7 = acc[7];
+  float r8 = acc[8], r9 = acc[9], r10 = acc[10], r11 = acc[11], r12 = acc[12], r13 = acc[13], r14 = acc[14], r15 = acc[15];
+  asm volatile("s_nop 1\n\t" EEC_SWAP8("16") EEC_SWAP8("32") "s_nop 1"
+               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(r8), "+v"(r9), "+v"(r10), "+v"(r11),
+                 "+v"(r12), "+v"(r13), "+v"(r14), "+v"(r15));
+  acc = (f32x16){r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
+}
+__device__ __forceinline__ void acc_std_to_q(f32x16& acc) {
+  float r0 = acc[0], r1 = acc[1], r2 = acc[2], r3 = acc[3], r4 = acc[4], r5 = acc[5], r6 = acc[6], r7 = acc[7];
+  float r8 = acc[8], r9 = acc[9], r10 = acc[10], r11 = acc[11], r12 = acc[12], r13 = acc[13], r14 = acc[14], r15 = acc[15];
+  asm volatile("s_nop 1\n\t" EEC_SWAP8("32") EEC_SWAP8("16") "s_nop 1"
+               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(r8), "+v"(r9), "+v"(r10), "+v"(r11),
+                 "+v"(r12), "+v"(r13), "+v"(r14), "+v"(r15));
+  acc = (f32x16){r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
+}
+template <int MT, int NT>
+__device__ __forceinline__ void accs_q_to_std(f32x16 (&acc)[MT][NT]) {
+  // the swaps below are inline asm: hipcc does not pad the MFMA-result -> VALU-read hazard in front of them (with a single tile
+  // the last MFMA's quadrant was read stale: tools/mfma16_gemm_check.hip).  19 wait states cover a 16-pass MFMA.
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc_q_to_std(acc[a][b]);
+}
+template <int MT, int NT>
+__device__ __forceinline__ void accs_std_to_q(f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) acc_std_to_q(acc[a][b]);
+}
+// per-lane bases of the 16x16x32 fragments, derived from the 32x32x16 ones the callers pass (a_lane = plane + (lane & 31) * ld +
+// 16 hh;  w_lane = fragment base + lane)
+__device__ __forceinline__ const char* a_lane16(const char* a_lane, int ld_bytes) {
+  const int lane = lane_id(), hh = lane >> 5, u = (lane >> 4) & 1;
+  return a_lane + u * (16 - 16 * ld_bytes) + hh * 16;
+}
+__device__ __forceinline__ const uint4* w_lane16(const uint4* w_lane) {
+  const int lane = lane_id(), hh = lane >> 5, u = (lane >> 4) & 1;
+  return w_lane + 96 * hh + 16 * u;
+}
+
+template <int NP, int PF, int NT>
+__device__ __forceinline__ void ring_fill_16(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride, int steps_avail) {
+  static_assert(PF % 2 == 0, "the ring is dealt in double k-steps");
+  const uint4* w16 = w_lane16(w_lane);
+#ifdef EEC_ABLATE_W
+  if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
+#endif
+#pragma unroll
+  for (int p = 0; p < PF; ++p)
+    if (p < steps_avail) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        r.q[p][nt][0] = w16[nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256];
+        if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = w16[nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256 + 64];
+      }
+    }
+  __builtin_amdgcn_sched_barrier(0);  // keep these loads HERE: one stage ahead of their consumer
+}
+
+// gemm_ring on the 16x16x32 shape.  IN_STD / OUT_STD: the accumulators arrive / leave in the standard layout (converted here);
+// false: they arrive / stay in the quadrant layout (a caller that accumulates over several calls converts once at the end).
+// The loop walks HALF double-steps p = 2 S + rb: step p multiplies row block rb of the activation operand (one fragment set: the
+// same registers per step as the 32x32x16 loop's k-step) with both row blocks of the weight operand (ring entries 2 S, 2 S + 1),
+// i.e. the two quadrants of each tile that row block rb of the activations belongs to.
+__device__ __forceinline__ void quad_mac16(f32x16& acc, int ra, int cb, h8 a, h8 b) {  // ra, cb constants after unrolling
+  const int q = 4 * (2 * ra + cb);
+  f32x4 t = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
+  t = mfma32(a, b, t);
+  acc[q] = t[0], acc[q + 1] = t[1], acc[q + 2] = t[2], acc[q + 3] = t[3];
+}
+template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int MT = 2, bool IN_STD = true, bool OUT_STD = true>
+__device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                             const uint4* __restrict__ w_lane, size_t nt_stride, WRing<NP, PF, NT>& r, Side side = Side()) {
+  static_assert(KS % 2 == 0 && PF % 2 == 0, "double k-steps");
+  constexpr int LO = (NP == 3) ? 1 : 0;
+  const char* a16 = a_lane16(a_lane, ld_bytes);
+  const uint4* w16 = w_lane16(w_lane);
+  if constexpr (IN_STD) accs_std_to_q<MT, NT>(acc);
+  h8 ah[2][MT], al[2][MT];  // [buffer][mt]: row block p & 1 of double step p >> 1
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    ah[0][mt] = *(const h8*)(a16 + mt * 32 * ld_bytes);
+    if (NP == 3) al[0][mt] = *(const h8*)(a16 + plane_bytes + mt * 32 * ld_bytes);
+  }
+#pragma unroll
+  for (int p = 0; p < KS; ++p) {
+    const int S = p >> 1, rb = p & 1, cur = p & 1, nxt = cur ^ 1;
+#ifdef EEC_ABLATE_A
+    if (p == 0) {
+#else
+    if (p + 1 < KS) {
+#endif
+      const int off = (16 * ((p + 1) & 1)) * ld_bytes + ((p + 1) >> 1) * 64;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        ah[nxt][mt] = *(const h8*)(a16 + mt * 32 * ld_bytes + off);
+        if (NP == 3) al[nxt][mt] = *(const h8*)(a16 + plane_bytes + mt * 32 * ld_bytes + off);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads BEFORE this step's MFMAs
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int wb = 0; wb < 2; ++wb) {  // row block of the weight operand
+        const h8 bh = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][0]);
+        const h8 bl = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][LO]);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          if (!SWAP) {  // A = activations (row block rb), B = weights (row block wb)
+            if (NP == 3) {
+              quad_mac16(acc[mt][nt], rb, wb, al[cur][mt], bh);
+              quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bl);
+            }
+            quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bh);
+          } else {      // A = weights, B = activations
+            if (NP == 3) {
+              quad_mac16(acc[mt][nt], wb, rb, bh, al[cur][mt]);
+              quad_mac16(acc[mt][nt], wb, rb, bl, ah[cur][mt]);
+            }
+            quad_mac16(acc[mt][nt], wb, rb, bh, ah[cur][mt]);
+          }
+        }
+      }
+    }
+    if (rb == 1) {  // both entries of double step S are consumed: refill them PF / 2 double steps ahead
+#ifdef EEC_ABLATE_W
+      if (false) {
+#else
+      if (2 * S + PF < KS) {
+#endif
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int wb = 0; wb < 2; ++wb) {
+            r.q[(2 * S + wb) % PF][nt][0] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256];
+#ifdef EEC_X3_LO_SKIP
+            if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = r.q[(2 * S + wb) % PF][nt][0];
+#else
+            if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256 + 64];
+#endif
+          }
+      }
+    }
+    side(p);
+    if (SIDE_VALU > 0) {
+#pragma unroll
+      for (int i = 0; i < MT * NT * NP; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // two 16x16x32 MFMAs (= one 32x32x16)
+        __builtin_amdgcn_sched_group_barrier(0x002, SIDE_VALU, 0);  // then SIDE_VALU VALU (incl. transcendental)
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (OUT_STD) accs_q_to_std<MT, NT>(acc);
+}
+
+// runtime (even) k-step count, no ring: ragged tails only
+template <int NP, int NT, bool SWAP, int MT = 2, bool IN_STD = true, bool OUT_STD = true>
+__device__ __forceinline__ void gemm_plain_16(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                              const uint4* __restrict__ w_lane, size_t nt_stride, int ks) {
+  const char* a16 = a_lane16(a_lane, ld_bytes);
+  const uint4* w16 = w_lane16(w_lane);
+  if constexpr (IN_STD) accs_std_to_q<MT, NT>(acc);
+  for (int S = 0; S < ks / 2; ++S) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      h8 bh[2], bl[2];
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb) {
+        bh[rb] = __builtin_bit_cast(h8, w16[nt * nt_stride + 16 * rb + (size_t)S * 256]);
+        bl[rb] = bh[rb];
+        if (NP == 3) bl[rb] = __builtin_bit_cast(h8, w16[nt * nt_stride + 16 * rb + (size_t)S * 256 + 64]);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        h8 ah[2], al[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          ah[rb] = *(const h8*)(a16 + (mt * 32 + 16 * rb) * ld_bytes + S * 64);
+          al[rb] = ah[rb];
+          if (NP == 3) al[rb] = *(const h8*)(a16 + plane_bytes + (mt * 32 + 16 * rb) * ld_bytes + S * 64);
+        }
+        if (NP == 3) {
+          if (SWAP) tile_mac16(acc[mt][nt], bh, al), tile_mac16(acc[mt][nt], bl, ah);
+          else tile_mac16(acc[mt][nt], al, bh), tile_mac16(acc[mt][nt], ah, bl);
+        }
+        if (SWAP) tile_mac16(acc[mt][nt], bh, ah);
+        else tile_mac16(acc[mt][nt], ah, bh);
+      }
+    }
+  }
+  if constexpr (OUT_STD) accs_q_to_std<MT, NT>(acc);
+}
+
+// The names the kernels use: the 16x16x32 forms for the split format NP = 3 (-DEEC_MFMA16=0: the 32x32x16 forms everywhere).
+// NP = 1 keeps 32x32x16: with a third of the MFMAs per SiLU the producers are VALU-bound, and a 16x16x32 MFMA holds the SIMD's
+// vector issue for 8 of its 16 cycles instead of 8 of 32 (measured: `mixed` 27.0 -> 22.9 M, `f16` 30.3 -> 23.9 M frames/s).
+// IN_STD / OUT_STD only matter for the 16x16x32 forms (the 32x32x16 accumulators are always in the standard layout).
+template <int NP>
+constexpr bool kMfma16For = (EEC_MFMA16 != 0) && NP == 3;
+template <int NP, int PF, int NT>
+__device__ __forceinline__ void ring_fill(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride, int steps_avail) {
+  if constexpr (kMfma16For<NP>) ring_fill_16<NP, PF, NT>(r, w_lane, nt_stride, steps_avail);
+  else ring_fill_32<NP, PF, NT>(r, w_lane, nt_stride, steps_avail);
+}
+template <int NP, int KS, int NT, bool SWAP, int PF, typename Side = NoSide, int SIDE_VALU = 0, int MT = 2, bool IN_STD = true, bool OUT_STD = true>
+__device__ __forceinline__ void gemm_ring(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                          const uint4* __restrict__ w_lane, size_t nt_stride, WRing<NP, PF, NT>& r, Side side = Side()) {
+  if constexpr (kMfma16For<NP>) gemm_ring_16<NP, KS, NT, SWAP, PF, Side, SIDE_VALU, MT, IN_STD, OUT_STD>(acc, a_lane, ld_bytes, plane_bytes, w_lane, nt_stride, r, side);
+  else gemm_ring_32<NP, KS, NT, SWAP, PF, Side, SIDE_VALU, MT>(acc, a_lane, ld_bytes, plane_bytes, w_lane, nt_stride, r, side);
+}
+template <int NP, int NT, bool SWAP, int MT = 2, bool IN_STD = true, bool OUT_STD = true>
+__device__ __forceinline__ void gemm_plain(f32x16 (&acc)[MT][NT], const char* a_lane, int ld_bytes, int plane_bytes,
+                                           const uint4* __restrict__ w_lane, size_t nt_stride, int ks) {
+  if constexpr (kMfma16For<NP>) gemm_plain_16<NP, NT, SWAP, MT, IN_STD, OUT_STD>(acc, a_lane, ld_bytes, plane_bytes, w_lane, nt_stride, ks);
+  else gemm_plain_32<NP, NT, SWAP, MT>(acc, a_lane, ld_bytes, plane_bytes, w_lane, nt_stride, ks);
 }
 
 // ===========================================================================

@@ -48,12 +48,14 @@ struct FfnGeo {
 // 128 KiB -> 28 TB/s), so the rings are as deep as the register budget allows.
 #ifndef EEC_PF1_NP3
 #define EEC_PF1_NP3 8
-#define EEC_PF2_NP3 4
+// (4 with the 32x32x16 k-loops; the 16x16x32 consumer loop of the split format needs a few registers more, and with four steps
+// in flight it spilled 35 of them into the chunk loop: same-box A/B 217.3 us per chain launch with 4, 214.3 us with 2)
+#define EEC_PF2_NP3 (EEC_MFMA16 ? 2 : 4)
 #define EEC_PF1_NP1 12
 #define EEC_PF2_NP1 8
 #endif
 // (D = 512: a consumer's ring holds 4 column tiles per k-step instead of 2, so it is half as deep)
-template <int D, int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = D == 512 ? EEC_PF2_NP3 / 2 : EEC_PF2_NP3; };
+template <int D, int NP> struct FfnPf { static constexpr int P1 = EEC_PF1_NP3, P2 = (D == 512 && EEC_PF2_NP3 > 2) ? EEC_PF2_NP3 / 2 : EEC_PF2_NP3; };
 template <int D> struct FfnPf<D, 1> { static constexpr int P1 = EEC_PF1_NP1, P2 = D == 512 ? EEC_PF2_NP1 / 2 : EEC_PF2_NP1; };
 #ifndef EEC_PF1_NP8
 #define EEC_PF1_NP8 6
@@ -294,6 +296,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
 #endif
 #endif
   constexpr int RNP = NP == 8 ? 1 : NP;  // the f8 stream keeps only the hi fragments in the ring
+  // split format (NP = 3): the products run on the 16x16x32 shape and the accumulators live in the quadrant layout inside
+  // the chunk loops (eec_device.h, EEC_MFMA16); NP = 1 and the f8 stream keep the 32x32 shapes and the standard layout
+  constexpr bool Q16 = kMfma16For<NP>;
   // Everything below is instantiated ONCE PER ROLE (the tag is a compile-time bool) and the role split is the
   // outermost branch: each role then carries only its own rings and accumulators through the stage loop
   // (with the split inside the loop the register allocator keeps both roles' state live: ~600 spilled VGPRs).
@@ -403,7 +408,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // and written to H[c & 1] in slot c+1 -- inside the k-loop of GEMM1(c+1), two values per k-step in
     // the shadow of that step's MFMAs -- and consumed (GEMM2) in slot c+2.
     if constexpr (producer) {
-      // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator
+      // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator.  Standard layout: register quad
+      // g = q >> 1 of lane (hh, r32) is hidden units 8 g + 4 hh .. + 3 of frame r32.  Quadrant layout (Q16): quad g = 2 ra + cb is
+      // hidden units 16 ra + 8 hh + 4 u .. + 3 of frame 16 cb + (lane & 15) -- either way four consecutive halves of one H row.
       auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
         const int mt = step >> 3, q = step & 7;
         const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
@@ -418,7 +425,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
           keep_hi = sp.hi;
           keep_lo = sp.lo;
         } else {
-          char* dst = hb + (mt * 32 + (lane & 31)) * kHLd + (wl * 32 + 4 * hh) * 2 + (q >> 1) * 16;
+          const int g = q >> 1;
+          const int frame = Q16 ? mt * 32 + 16 * (g & 1) + (lane & 15) : mt * 32 + (lane & 31);
+          const int hid = Q16 ? wl * 32 + 16 * (g >> 1) + 8 * hh + 4 * ((lane >> 4) & 1) : wl * 32 + 4 * hh + g * 8;
+          char* dst = hb + frame * kHLd + hid * 2;
           h4 hi, lo;
           hi.xy = keep_hi, hi.zw = sp.hi, lo.xy = keep_lo, lo.zw = sp.lo;
           *(h4*)dst = hi;
@@ -433,6 +443,23 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
         }
       };
       auto init_bias = [&](f32x16 (&acc)[MT][1], int ft) {
+        if constexpr (Q16) {  // quadrant layout: register 4 (2 ra + cb) + i <-> hidden unit 16 ra + 8 hh + 4 u + i
+          const int u = (lane >> 4) & 1;
+#pragma unroll
+          for (int ra = 0; ra < 2; ++ra) {
+            const float4 bb = *(const float4*)(b1s + ft * 32 + 16 * ra + 8 * hh + 4 * u);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {
+                acc[mt][0][4 * (2 * ra + cb) + 0] = bb.x;
+                acc[mt][0][4 * (2 * ra + cb) + 1] = bb.y;
+                acc[mt][0][4 * (2 * ra + cb) + 2] = bb.z;
+                acc[mt][0][4 * (2 * ra + cb) + 3] = bb.w;
+              }
+          }
+          return;
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const float4 bb = *(const float4*)(b1s + ft * 32 + 8 * g + 4 * hh);
@@ -466,14 +493,14 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
               gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(
                   cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
-              gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7), MT>(cur, a_lane, kALd, kAPlane, w1_lane,
-                                                                                      0, r1, side);
+              gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7), MT, !Q16, !Q16>(cur, a_lane, kALd, kAPlane, w1_lane,
+                                                                                                  0, r1, side);
           } else {
             if constexpr (NP == 8)
               gemm_ring_f8<D / 64, 1, true, kPF1, NoSide, 0, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(cur, a_lane, kALd, a8_lane, kA8Ld,
                                                                                                                     w1f8_lane(W, ft), 0, r1, wg1);
             else
-              gemm_ring<RNP, KS, 1, true, kPF1, NoSide, 0, MT>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
+              gemm_ring<RNP, KS, 1, true, kPF1, NoSide, 0, MT, !Q16, !Q16>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
           }
           if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(W, phys(s + 1) * 4 + wl);  // next chunk's W1 stream
         } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
@@ -543,9 +570,9 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
               }
             }
           } else if (ks2 == kFC / 16) {
-            gemm_ring<RNP, kFC / 16, NTP, false, kPF2, NoSide, 0, MT>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
+            gemm_ring<RNP, kFC / 16, NTP, false, kPF2, NoSide, 0, MT, !Q16, !Q16>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, r2);
           } else {
-            gemm_plain<RNP, NTP, false, MT>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
+            gemm_plain<RNP, NTP, false, MT, !Q16, !Q16>(acc2c[0], h_lane, kHLd, kHPlane, w2_lane, w2_nt_stride, ks2);
           }
           if (NH == 1 && cl + 1 < nchunk) fill2(W, phys(cl + 1));  // next chunk's W2 stream: in flight across the barrier
         }
@@ -577,6 +604,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
     // loops guarantees that nobody still reads the H buffers it aliases)
     TL_STAMP();  // residual loads issued
     if constexpr (!producer) {
+      if constexpr (Q16) {  // the chunk loops kept the accumulators in the quadrant layout: back to the standard one, once
+#pragma unroll
+        for (int h = 0; h < NH; ++h) accs_q_to_std<MT, NTP>(acc2c[h]);
+      }
 #pragma unroll
       for (int h = 0; h < NH; ++h)
         acc_to_etile<MT, NTP>(lds_e, G::kELd, acc2c[h], wl_s * 32 * NT2 + h * 32 * NTP, EEC_STAGE_FIELD(si, b2), lane_e);

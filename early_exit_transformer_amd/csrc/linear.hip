@@ -116,8 +116,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_residual_kernel(ProjResAr
   }
   __syncthreads();
   f32x16 acc[1][NW];
-  acc_init_bias<1, NW>(acc, a.bias + 32 * NW * w);
-  gemm_ring<NP, G::kKS, NW, true, kLPF, NoSide, 0, 1>(acc, a_lane, G::kALd, PLANE, wfrag_lane<G::kKS>(a.wp, NW * w),
+  acc_init_bias_np<NP, 1, NW>(acc, a.bias + 32 * NW * w);
+  gemm_ring<NP, G::kKS, NW, true, kLPF, NoSide, 0, 1, !kMfma16For<NP>, true>(acc, a_lane, G::kALd, PLANE, wfrag_lane<G::kKS>(a.wp, NW * w),
                                                       (size_t)G::kKS * 128, r);
   acc_swapped_add_rows<D, 1, NW>(a.x, row0, a.M, acc, 32 * NW * w);
 }
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   EEC_TL_STAMP(glu, 2);
   {
     f32x16 acc[MT][NW];
-    acc_init_bias<MT, NW>(acc, a.bias + 32 * NW * w);
+    acc_init_bias_np<NP, MT, NW>(acc, a.bias + 32 * NW * w);
     proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, r, wo, NW * w);
     EEC_TL_STAMP(glu, 3);
     proj_fill<D, NP, kLPF, NW>(rv, wg, NW * w);  // GLU value weights: in flight during the exchange
@@ -400,10 +400,10 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   ProjStream<NP, kLPF, NW> rg;
   proj_fill<D, NP, kLPF, NW>(rg, wg, TQ + NW * w);
   f32x16 av[MT][NW], ag[MT][NW];
-  acc_init_bias<MT, NW>(av, gl.bias + 32 * NW * w);
+  acc_init_bias_np<NP, MT, NW>(av, gl.bias + 32 * NW * w);
   proj_gemm<D, NP, kLPF, NW, MT>(av, smem, rv, wg, NW * w);
   EEC_TL_STAMP(glu, 8);
-  acc_init_bias<MT, NW>(ag, gl.bias + D + 32 * NW * w);
+  acc_init_bias_np<NP, MT, NW>(ag, gl.bias + D + 32 * NW * w);
   proj_gemm<D, NP, kLPF, NW, MT>(ag, smem, rg, wg, TQ + NW * w);
   EEC_TL_STAMP(glu, 9);
 #pragma unroll
@@ -472,7 +472,7 @@ __device__ __forceinline__ void head_body(char* smem, const HeadArgs& a) {
   __syncthreads();
   f32x16 acc[MT][1];
   if (active) {
-    acc_init_bias<MT, 1>(acc, a.bias + 32 * w);
+    acc_init_bias_np<NP, MT, 1>(acc, a.bias + 32 * w);
     proj_gemm<D, NP, kLPF, 1, MT>(acc, smem, r, wm, w);
   }
   // logits -> fp32 exchange tile (over the dead activation planes) -> each wave finishes RPW whole frames: the

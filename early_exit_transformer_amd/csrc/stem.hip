@@ -47,7 +47,7 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleAr
   WRing<NP, kSPF, NW> r;
   const uint4* w_lane = a.w1p + (size_t)(NW * w) * ks * 128 + lane;
   const size_t nts = (size_t)ks * 128;
-  ring_fill<NP, kSPF, NW>(r, w_lane, nts, ks);
+  ring_fill_32<NP, kSPF, NW>(r, w_lane, nts, ks);  // consumed by gemm_plain_ring (32x32x16 fragments)
   unsigned* row_max = (unsigned*)(smem + 2 * plane);  // [64] input rows, [64] output rows: |max| as fp32 bit patterns
   if (threadIdx.x < 2 * kStemRows1) row_max[threadIdx.x] = 0u;
   // stage A: thread = (row rr, channel group cg); 3 taps per (row, ci); the row's scale comes from its own maximum
