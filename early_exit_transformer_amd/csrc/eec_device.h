@@ -530,29 +530,48 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
       }
       __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads BEFORE this step's MFMAs
     }
+#ifndef EEC_MFMA16_ORDER
+#define EEC_MFMA16_ORDER 1  // 1: product-major (consecutive MFMAs go to different quadrants); 0: quadrant-major (three dependent products in a row)
+#endif
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
+      h8 bh[2], bl[2];
 #pragma unroll
       for (int wb = 0; wb < 2; ++wb) {  // row block of the weight operand
-        const h8 bh = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][0]);
-        const h8 bl = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][LO]);
+        bh[wb] = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][0]);
+        bl[wb] = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][LO]);
+      }
+#if EEC_MFMA16_ORDER
+#pragma unroll
+      for (int pr = (NP == 3 ? 0 : 2); pr < 3; ++pr)  // a_lo . w_hi, a_hi . w_lo, a_hi . w_hi
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int wb = 0; wb < 2; ++wb) {
+            const h8 a = pr == 0 ? al[cur][mt] : ah[cur][mt], w = pr == 1 ? bl[wb] : bh[wb];
+            if (!SWAP) quad_mac16(acc[mt][nt], rb, wb, a, w);  // A = activations (row block rb), B = weights (row block wb)
+            else quad_mac16(acc[mt][nt], wb, rb, w, a);        // A = weights, B = activations
+          }
+#else
+#pragma unroll
+      for (int wb = 0; wb < 2; ++wb)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-          if (!SWAP) {  // A = activations (row block rb), B = weights (row block wb)
+          if (!SWAP) {
             if (NP == 3) {
-              quad_mac16(acc[mt][nt], rb, wb, al[cur][mt], bh);
-              quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bl);
+              quad_mac16(acc[mt][nt], rb, wb, al[cur][mt], bh[wb]);
+              quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bl[wb]);
             }
-            quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bh);
-          } else {      // A = weights, B = activations
+            quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bh[wb]);
+          } else {
             if (NP == 3) {
-              quad_mac16(acc[mt][nt], wb, rb, bh, al[cur][mt]);
-              quad_mac16(acc[mt][nt], wb, rb, bl, ah[cur][mt]);
+              quad_mac16(acc[mt][nt], wb, rb, bh[wb], al[cur][mt]);
+              quad_mac16(acc[mt][nt], wb, rb, bl[wb], ah[cur][mt]);
             }
-            quad_mac16(acc[mt][nt], wb, rb, bh, ah[cur][mt]);
+            quad_mac16(acc[mt][nt], wb, rb, bh[wb], ah[cur][mt]);
           }
         }
-      }
+#endif
     }
     if (rb == 1) {  // both entries of double step S are consumed: refill them PF / 2 double steps ahead
 #ifdef EEC_ABLATE_W

@@ -50,6 +50,22 @@ def test_native_library_is_loaded():
     assert any("libeec.so" in line for line in open("/proc/self/maps"))
 
 
+def test_mfma16_gemm_forms_equal_the_32x32_forms():
+    """Device check of the k-loops of the default (split) format: the 16x16x32 forms (re-addressed fragments of the same
+    packing, quadrant accumulators restored by lane swaps; csrc/eec_device.h, EEC_MFMA16) against the 32x32x16 forms on the
+    same LDS planes, packed weights and rings -- both orientations, 1 / 2 row tiles, 1 / 2 column tiles, ring refills.  Built
+    by `make` (csrc/build/mfma16_gemm_check); exits non-zero if any accumulator element differs by more than 1e-4."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "early_exit_transformer_amd", "csrc", "build", "mfma16_gemm_check")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.dirname(os.path.dirname(exe)), "build/mfma16_gemm_check"], check=True, capture_output=True)
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    print(res.stdout)
+    assert res.returncode == 0 and res.stdout.count(" OK") >= 8 and "FAIL" not in res.stdout, res.stdout + res.stderr
+
+
 def logp_tolerance(prec, want_logp):
     """The default mode (FLAT_MODES): the north-star tolerance, flat -- |dlogp| <= 1e-3 whatever the outputs look like.
     The opt-in faster modes state a weaker bound: |dlogp| <= TOL[prec] * max(1, max|logp| / LOGP_UNIT) -- their operand
