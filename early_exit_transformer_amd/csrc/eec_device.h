@@ -601,6 +601,9 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef EEC_KSTEP_STAMPS
+    if (NT == 2) eec_kstep_stamp();
+#endif
   }
   if constexpr (OUT_STD) accs_q_to_std<MT, NT>(acc);
 }

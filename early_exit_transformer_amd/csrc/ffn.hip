@@ -246,7 +246,10 @@ __global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) 
   // wave-uniform.  The producers are the OLDER waves (0-3): issue arbitration between the two waves of a SIMD goes by
   // priority, then age, and the producers are the critical path of the chunk pipeline (measured -2.3 % forward against
   // the opposite assignment; raising their priority with s_setprio instead makes it slower)
-  const bool is_producer = EEC_ROLE_PAIR ? (w & 2) == 0 : w < 4;
+#ifndef EEC_PROD_YOUNG
+#define EEC_PROD_YOUNG 0  // experiment: 1 = in the split format (NP = 3) the CONSUMERS are the older waves (0-3)
+#endif
+  const bool is_producer = EEC_ROLE_PAIR ? (w & 2) == 0 : ((EEC_PROD_YOUNG && NP == 3) ? w >= 4 : w < 4);
   const int row0 = row_tile_index() * G::kRows;
   const int M = a.M, F = a.F;
   float* __restrict__ x = a.x;
