@@ -259,7 +259,8 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     at.q_lo = b.q_lo, at.k_lo = b.k_lo;
     ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
     GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g, L.conv_pw1_f8};
-    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1) && !b.q_lo) {
+    // (exact mode: Q / K residual planes present -> the fused launch runs its three-product attention, which needs glu format 3)
+    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1) && (!b.q_lo || np.glu == 3)) {
       // two launches per layer: the attention of a row tile runs in the prologue of the out_proj / GLU kernel
       TIMED(KC_PROJ_GLU, launch_attn_proj_glu(at, pr, ga, np.glu, st));
     } else {

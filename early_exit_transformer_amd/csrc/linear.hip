@@ -152,10 +152,14 @@ constexpr int kProjGluLds = 2 * Geo<D>::kAPlane + Geo<D>::kETile;  // 134144 / 1
 // 64-B-per-row pieces, read by the four workgroups of the utterance out of L2), double-buffered in registers: there is
 // no LDS staging, no barrier, and the normalised O never leaves the CU -- it is split hi / lo and written into the
 // LDS planes at columns [32 w .. ) of the tile's rows.
-template <int D, int NP>
+// X3 (exact mode f16x3, round 4): Q and K arrive with fp16 residual planes and the probabilities are split hi / lo in registers,
+// so both products run as three fp16 MFMA products like every GEMM of the mode (what attn_kernel<.., 3, true> does in its own
+// launch, with K and its residual staged in LDS).  The second fragment set costs the registers of one key tile: blocks of 32 keys
+// instead of 64.
+template <int D, int NP, bool X3 = false>
 __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& a, int row0) {
   using G = Geo<D>;
-  constexpr int MT = G::kMT, DH = D / 8, KSQ = DH / 16, DT = DH / 32, KB = 2;
+  constexpr int MT = G::kMT, DH = D / 8, KSQ = DH / 16, DT = DH / 32, KB = X3 ? 1 : 2;
   constexpr float kNegBig = -1.0e30f;
   const int lane = lane_id(), w = wave_id(), r = lane & 31, hh = lane >> 5;
   const int b = row0 / a.Tq, q0 = row0 - b * a.Tq, bh = b * a.H + w;
@@ -163,11 +167,15 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   int len = 0, nkt = 0;
   const bool v2 = a.vt_lo != nullptr;  // uniform
   h8 qf[MT][KSQ];
+  [[maybe_unused]] h8 qfl[MT][KSQ];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const half_t* qp = a.q + ((size_t)bh * a.Tp + q0 + mt * 32 + r) * DH + 8 * hh;
+    const size_t qoff = ((size_t)bh * a.Tp + q0 + mt * 32 + r) * DH + 8 * hh;
 #pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) qf[mt][ks] = *(const h8*)(qp + ks * 16);
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[mt][ks] = *(const h8*)(a.q + qoff + ks * 16);
+      if constexpr (X3) qfl[mt][ks] = *(const h8*)(a.q_lo + qoff + ks * 16);
+    }
   }
   f32x16 o[MT][DT];
   float m_run[MT], l_run[MT];
@@ -182,8 +190,9 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   const half_t* kbase = a.k + (size_t)bh * a.Tp * DH;
   const half_t* vbase = a.vt + (size_t)bh * DH * a.Tp;
   const half_t* vlbase = v2 ? a.vt_lo + (size_t)bh * DH * a.Tp : vbase;
-  struct Blk {  // K and V^T fragments of one block of KB key tiles
-    h8 k[KB][KSQ], v[KB][DT][2], vl[KB][DT][2];
+  [[maybe_unused]] const half_t* klbase = X3 ? a.k_lo + (size_t)bh * a.Tp * DH : kbase;
+  struct Blk {  // K and V^T fragments of one block of KB key tiles (X3: K's residual too)
+    h8 k[KB][KSQ], v[KB][DT][2], vl[KB][DT][2], kl[X3 ? KB : 1][X3 ? KSQ : 1];
   };
   const h8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
   // `last`: the last tile that may be read (a tile past the utterance's keys is re-read and masked away below).  The FIRST
@@ -195,7 +204,10 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
     for (int j = 0; j < KB; ++j) {
       const int kt = min(kt0 + j, last);
 #pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) f.k[j][ks] = *(const h8*)(kbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
+      for (int ks = 0; ks < KSQ; ++ks) {
+        f.k[j][ks] = *(const h8*)(kbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
+        if constexpr (X3) f.kl[j][ks] = *(const h8*)(klbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
+      }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -215,7 +227,13 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
 #pragma unroll
         for (int i = 0; i < 16; ++i) sc[j][mt][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KSQ; ++ks) sc[j][mt] = mfma16(f.k[j][ks], qf[mt][ks], sc[j][mt]);
+        for (int ks = 0; ks < KSQ; ++ks) {
+          if constexpr (X3) {  // the two correction products first, the main product last (as the GEMMs of this mode)
+            sc[j][mt] = mfma16(f.kl[j][ks], qf[mt][ks], sc[j][mt]);
+            sc[j][mt] = mfma16(f.k[j][ks], qfl[mt][ks], sc[j][mt]);
+          }
+          sc[j][mt] = mfma16(f.k[j][ks], qf[mt][ks], sc[j][mt]);
+        }
       }
     const int key0 = kt0 * 32;
     if (key0 + KB * 32 > len) {  // block touches the masked tail (or runs past the last tile): wave-uniform test
@@ -241,13 +259,16 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
       m_run[mt] = m_new;
       float psum = 0.f;
       h8 pf[KB][2];
+      [[maybe_unused]] h8 pfl[KB][2];
 #pragma unroll
       for (int j = 0; j < KB; ++j)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float p = __builtin_amdgcn_exp2f(sc[j][mt][i] - m_new);
           psum += p;
-          pf[j][i >> 3][i & 7] = (half_t)p;
+          const half_t ph = (half_t)p;
+          pf[j][i >> 3][i & 7] = ph;
+          if constexpr (X3) pfl[j][i >> 3][i & 7] = (half_t)(p - (float)ph);
         }
       l_run[mt] = l_run[mt] * alpha + psum;
 #pragma unroll
@@ -258,8 +279,9 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
         for (int j = 0; j < KB; ++j)
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            o[mt][dt] = mfma16(f.v[j][dt][ks], pf[j][ks], o[mt][dt]);
             if (v2) o[mt][dt] = mfma16(f.vl[j][dt][ks], pf[j][ks], o[mt][dt]);
+            if constexpr (X3) o[mt][dt] = mfma16(f.v[j][dt][ks], pfl[j][ks], o[mt][dt]);
+            o[mt][dt] = mfma16(f.v[j][dt][ks], pf[j][ks], o[mt][dt]);
           }
       }
     }
@@ -327,7 +349,8 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
 
 // FUSED: the tile's attention runs in the prologue (attn_tile_to_planes) instead of loading the O planes a separate
 // attention launch wrote: two launches per Conformer layer instead of three, no O round trip through HBM.
-template <int D, int NP, bool FUSED>
+// FUSED: 0 = the O planes come from a separate attention launch; 1 = fused attention; 2 = fused attention of the exact mode (X3)
+template <int D, int NP, int FUSED>
 __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a, GluArgs gl, AttnArgs at) {
   using G = Geo<D>;
   constexpr int MT = G::kMT, NW = G::kNW, RPW = G::kRPW;
@@ -339,8 +362,8 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   const WMat wo{a.wp, a.wf8}, wg{gl.wp, gl.wf8};
   EEC_TL_STAMP(glu, 0);
   RowV<G::kQ> xres[RPW];
-  if constexpr (FUSED) {
-    attn_tile_to_planes<D, NP>(smem, at, row0);
+  if constexpr (FUSED != 0) {
+    attn_tile_to_planes<D, NP, FUSED == 2>(smem, at, row0);
     proj_fill<D, NP, kLPF, NW>(r, wo, NW * w);
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -429,9 +452,14 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   EEC_TL_STAMP(glu, 10);
 }
 
-template <int D, bool FUSED>
+template <int D, int FUSED>
 static hipError_t launch_proj_glu_d(const ProjResArgs& a, const GluArgs& g, const AttnArgs& at, int np, hipStream_t st) {
-  auto k = np == 8 ? proj_glu_kernel<D, 8, FUSED> : np == 3 ? proj_glu_kernel<D, 3, FUSED> : proj_glu_kernel<D, 1, FUSED>;
+  auto k = proj_glu_kernel<D, 3, FUSED>;
+  if constexpr (FUSED == 2) {
+    if (np != 3) return hipErrorInvalidValue;  // the exact mode only
+  } else {
+    k = np == 8 ? proj_glu_kernel<D, 8, FUSED> : np == 3 ? proj_glu_kernel<D, 3, FUSED> : proj_glu_kernel<D, 1, FUSED>;
+  }
   hipError_t e = ensure_max_lds((const void*)k, kProjGluLds<D>);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(k, dim3((a.M + Geo<D>::kRows - 1) / Geo<D>::kRows), dim3(kLinThreads), kProjGluLds<D>, st, a, g, at);
@@ -439,7 +467,7 @@ static hipError_t launch_proj_glu_d(const ProjResArgs& a, const GluArgs& g, cons
 }
 hipError_t launch_proj_glu(const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
   const AttnArgs none{};
-  return a.D == 512 ? launch_proj_glu_d<512, false>(a, g, none, np, st) : launch_proj_glu_d<256, false>(a, g, none, np, st);
+  return a.D == 512 ? launch_proj_glu_d<512, 0>(a, g, none, np, st) : launch_proj_glu_d<256, 0>(a, g, none, np, st);
 }
 // attention + out_proj + LN + pointwise-1 + GLU in one launch; usable when attn_fusable() holds
 bool attn_fusable(const AttnArgs& at, int D) {
@@ -449,7 +477,11 @@ bool attn_fusable(const AttnArgs& at, int D) {
 }
 hipError_t launch_attn_proj_glu(const AttnArgs& at, const ProjResArgs& a, const GluArgs& g, int np, hipStream_t st) {
   if (!attn_fusable(at, a.D)) return hipErrorInvalidValue;
-  return launch_proj_glu_d<256, true>(a, g, at, np, st);
+  if (at.q_lo || at.k_lo) {  // exact mode: Q, K, V all with residual planes, three products per attention product
+    if (np != 3 || !at.q_lo || !at.k_lo || !at.vt_lo) return hipErrorInvalidValue;
+    return launch_proj_glu_d<256, 2>(a, g, at, np, st);
+  }
+  return launch_proj_glu_d<256, 1>(a, g, at, np, st);
 }
 
 // ---------------------------------------------------------------------------

@@ -375,11 +375,28 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
 #else
+#ifdef EECT_MFMA_SHAPE_TIMING  // timing-only build (WRONG results): the same MACs on v_mfma_f32_16x16x32_bf16, two quarters of the accumulator
+          {
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            f32x16& c = acc[mt][nt];
+            f32x4_t q0 = {c[0], c[1], c[2], c[3]}, q2 = {c[8], c[9], c[10], c[11]};
+            if (NP == 3) {
+              q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], q0, 0, 0, 0);
+              q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], q2, 0, 0, 0);
+              q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], q0, 0, 0, 0);
+              q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], q2, 0, 0, 0);
+            }
+            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], q0, 0, 0, 0);
+            q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], q2, 0, 0, 0);
+            c[0] = q0[0], c[1] = q0[1], c[2] = q0[2], c[3] = q0[3], c[8] = q2[0], c[9] = q2[1], c[10] = q2[2], c[11] = q2[3];
+          }
+#else
           if (NP == 3) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+#endif
 #endif
         }
     }
