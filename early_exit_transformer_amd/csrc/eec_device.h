@@ -530,59 +530,32 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
       }
       __builtin_amdgcn_sched_barrier(0);  // issue the next step's LDS reads BEFORE this step's MFMAs
     }
-#ifndef EEC_MFMA16_ORDER
-#define EEC_MFMA16_ORDER 1  // 1: product-major (consecutive MFMAs go to different quadrants); 0: quadrant-major (three dependent products in a row)
-#endif
+    // weight row block wb outermost: ring entry (S, wb) is finished -- and refilled PF / 2 double steps ahead -- as soon as its
+    // products of the step with rb == 1 are issued, half a step before the double step ends.  (With the refill at the end of the
+    // double step a two-entry ring had NO lead at all: the loads of double step S + 1 were requested when S + 1 began.)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      h8 bh[2], bl[2];
+    for (int wb = 0; wb < 2; ++wb) {
 #pragma unroll
-      for (int wb = 0; wb < 2; ++wb) {  // row block of the weight operand
-        bh[wb] = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][0]);
-        bl[wb] = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][LO]);
-      }
-#if EEC_MFMA16_ORDER
+      for (int nt = 0; nt < NT; ++nt) {
+        const h8 bh = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][0]);
+        const h8 bl = __builtin_bit_cast(h8, r.q[(2 * S + wb) % PF][nt][LO]);
 #pragma unroll
-      for (int pr = (NP == 3 ? 0 : 2); pr < 3; ++pr)  // a_lo . w_hi, a_hi . w_lo, a_hi . w_hi
+        for (int pr = (NP == 3 ? 0 : 2); pr < 3; ++pr)  // a_lo . w_hi, a_hi . w_lo, a_hi . w_hi
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int wb = 0; wb < 2; ++wb) {
-            const h8 a = pr == 0 ? al[cur][mt] : ah[cur][mt], w = pr == 1 ? bl[wb] : bh[wb];
+          for (int mt = 0; mt < MT; ++mt) {
+            const h8 a = pr == 0 ? al[cur][mt] : ah[cur][mt], w = pr == 1 ? bl : bh;
             if (!SWAP) quad_mac16(acc[mt][nt], rb, wb, a, w);  // A = activations (row block rb), B = weights (row block wb)
             else quad_mac16(acc[mt][nt], wb, rb, w, a);        // A = weights, B = activations
           }
-#else
-#pragma unroll
-      for (int wb = 0; wb < 2; ++wb)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          if (!SWAP) {
-            if (NP == 3) {
-              quad_mac16(acc[mt][nt], rb, wb, al[cur][mt], bh[wb]);
-              quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bl[wb]);
-            }
-            quad_mac16(acc[mt][nt], rb, wb, ah[cur][mt], bh[wb]);
-          } else {
-            if (NP == 3) {
-              quad_mac16(acc[mt][nt], wb, rb, bh[wb], al[cur][mt]);
-              quad_mac16(acc[mt][nt], wb, rb, bl[wb], ah[cur][mt]);
-            }
-            quad_mac16(acc[mt][nt], wb, rb, bh[wb], ah[cur][mt]);
-          }
-        }
-#endif
-    }
-    if (rb == 1) {  // both entries of double step S are consumed: refill them PF / 2 double steps ahead
+      }
+      if (rb == 1) {
 #ifdef EEC_ABLATE_W
-      if (false) {
+        if (false) {
 #else
-      if (2 * S + PF < KS) {
+        if (2 * S + PF < KS) {
 #endif
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int wb = 0; wb < 2; ++wb) {
+          for (int nt = 0; nt < NT; ++nt) {
             r.q[(2 * S + wb) % PF][nt][0] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256];
 #ifdef EEC_X3_LO_SKIP
             if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = r.q[(2 * S + wb) % PF][nt][0];
@@ -590,6 +563,7 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
             if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256 + 64];
 #endif
           }
+        }
       }
     }
     side(p);

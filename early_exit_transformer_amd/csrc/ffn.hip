@@ -224,7 +224,10 @@ __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, flo
 //   QNP  0: none;  else: the attention in_proj of the NEXT half-layer (format QNP) runs on the final rows
 //   NS   number of FFN stages (1 or 2)
 template <int D, int NP, int ACT, int FNP, int QNP, int NS>
-__global__ __launch_bounds__(kFfnThreads, 2) void ffn_chain_kernel(ChainArgs a) {
+#ifndef EEC_FFN_MINWAVES
+#define EEC_FFN_MINWAVES 2
+#endif
+__global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kernel(ChainArgs a) {
   using G = Geo<D>;
   using FG = FfnGeo<D>;
   constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS, RPW = G::kRPW, NT2 = FG::kNT2;
