@@ -203,6 +203,45 @@ __device__ __forceinline__ bf16x8 read_frag(const bf16* __restrict__ t, int rbas
   return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
+// The same tile images read as operands of v_mfma_f32_16x16x32_bf16 (EECT_MFMA16; csrc/eec_device.h has the inference path's form of
+// this): the chip holds a higher clock on that shape under load (profiles/r04_micro_mfma_shape_clock.txt; timing-only swap in this
+// kernel: training step 25.5 -> 24.1 ms).  Lane l = 16 g + c holds row rbase + 16 rb + c, k = 8 g .. 8 g + 7 of the 32-deep tile.
+#ifndef EECT_MFMA16
+#define EECT_MFMA16 1
+#endif
+template <int R, bool KC>
+__device__ __forceinline__ bf16x8 read_frag16(const bf16* __restrict__ t, int rbase, int rb, int lane) {
+  const int c = lane & 15, g = lane >> 4;
+  if (KC) return *(const bf16x8*)(t + (rbase + 16 * rb + c) * kLdk + g * 8);
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  const bf16* a = t + (8 * g + (c >> 2)) * TileGeo<R>::kLdt + rbase + 16 * rb + 4 * (c & 3);
+  const bf16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)a);
+  const bf16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(a + 4 * TileGeo<R>::kLdt));
+  return __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// quadrant (ra, cb) of a 32 x 32 tile (registers 4 (2 ra + cb) ..): m = 16 ra + 4 (lane >> 4) + i, n = 16 cb + (lane & 15)
+__device__ __forceinline__ void quad_mac16(f32x16& acc, int ra, int cb, bf16x8 a, bf16x8 b) {
+  const int q = 4 * (2 * ra + cb);
+  f32x4 t = {acc[q], acc[q + 1], acc[q + 2], acc[q + 3]};
+  t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, t, 0, 0, 0);
+  acc[q] = t[0], acc[q + 1] = t[1], acc[q + 2] = t[2], acc[q + 3] = t[3];
+}
+// quadrant layout -> the 32x32x16 layout the epilogues expect: v_permlane16_swap + v_permlane32_swap on the register pairs
+// (4 (2 ra) + i, 4 (2 ra + 1) + i), one asm block per tile (derivation and checks: csrc/eec_device.h, tools/mfma16_gemm_check.hip)
+#define EECT_SWAP8(OP)                                                                                                       \
+  "v_permlane" OP "_swap_b32 %0, %4\n\tv_permlane" OP "_swap_b32 %1, %5\n\tv_permlane" OP "_swap_b32 %2, %6\n\t"            \
+  "v_permlane" OP "_swap_b32 %3, %7\n\tv_permlane" OP "_swap_b32 %8, %12\n\tv_permlane" OP "_swap_b32 %9, %13\n\t"          \
+  "v_permlane" OP "_swap_b32 %10, %14\n\tv_permlane" OP "_swap_b32 %11, %15\n\t"
+__device__ __forceinline__ void acc_q_to_std(f32x16& acc) {
+  float r0 = acc[0], r1 = acc[1], r2 = acc[2], r3 = acc[3], r4 = acc[4], r5 = acc[5], r6 = acc[6], r7 = acc[7];
+  float r8 = acc[8], r9 = acc[9], r10 = acc[10], r11 = acc[11], r12 = acc[12], r13 = acc[13], r14 = acc[14], r15 = acc[15];
+  asm volatile("s_nop 1\n\t" EECT_SWAP8("16") EECT_SWAP8("32") "s_nop 1"
+               : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7), "+v"(r8), "+v"(r9), "+v"(r10), "+v"(r11),
+                 "+v"(r12), "+v"(r13), "+v"(r14), "+v"(r15));
+  acc = (f32x16){r0, r1, r2, r3, r4, r5, r6, r7, r8, r9, r10, r11, r12, r13, r14, r15};
+}
+
 // f(IntTag<0>{}), ..., f(IntTag<N - 1>{}): a loop whose index is a compile-time constant in the body (register arrays indexed by
 // it never fall back to scratch memory, whatever the unroller decides)
 template <int I>
@@ -350,7 +389,62 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
     store_tile<BN, NP, BKC>(b_hi + buf * kBufElems, b_lo + buf * kBufElems, rb, tid);
   };
   // the 32-deep k-tile in plane set `buf`: fragments from LDS, 4 x TM x TN x (1 or 3) MFMAs
+#ifndef EECT_MFMA16_KC_ONLY
+#define EECT_MFMA16_KC_ONLY 0  // 1: the 16x16x32 form only where both operands are k-contiguous (no spills there)
+#endif
+  constexpr bool kM16 = EECT_MFMA16 && EECT_EPI_DIRECT != 2 && (!EECT_MFMA16_KC_ONLY || (AKC && BKC));
   auto mfma_tile = [&](int buf) __attribute__((always_inline)) {
+#if EECT_MFMA16 && EECT_EPI_DIRECT != 2
+    if constexpr (kM16)
+    // 16x16x32 form: the 32-deep tile is ONE k-step.  Row block ra of A (fragments of every row tile, hi / lo) against row block cb of
+    // B, in the order (0,0) (0,1) (1,1) (1,0) so that a B fragment set is read three times, not four; the same eight fragment
+    // registers as a 16-deep step of the 32x32x16 form.
+    {
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+      auto load_a = [&](int ra) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+          ah[mt] = read_frag16<BM, AKC>(a_hi + buf * kBufElems, (wm * TM + mt) * 32, ra, lane);
+          if (NP == 3) al[mt] = read_frag16<BM, AKC>(a_lo + buf * kBufElems, (wm * TM + mt) * 32, ra, lane);
+        }
+      };
+      auto load_b = [&](int cb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) {
+          bh[nt] = read_frag16<BN, BKC>(b_hi + buf * kBufElems, (wn * TN + nt) * 32, cb, lane);
+          if (NP == 3) bl[nt] = read_frag16<BN, BKC>(b_lo + buf * kBufElems, (wn * TN + nt) * 32, cb, lane);
+        }
+      };
+      auto macs = [&](int ra, int cb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < TN; ++nt) {
+            if (NP == 3) {
+              quad_mac16(acc[mt][nt], ra, cb, al[mt], bh[nt]);
+              quad_mac16(acc[mt][nt], ra, cb, ah[mt], bl[nt]);
+            }
+            quad_mac16(acc[mt][nt], ra, cb, ah[mt], bh[nt]);
+          }
+      };
+      // (fenced: left alone, hipcc hoists every fragment read of the tile in front of the first MFMA -- 20 fragments live at once)
+      load_a(0);
+      load_b(0);
+      __builtin_amdgcn_sched_barrier(0);
+      macs(0, 0);
+      load_b(1);
+      __builtin_amdgcn_sched_barrier(0);
+      macs(0, 1);
+      load_a(1);
+      __builtin_amdgcn_sched_barrier(0);
+      macs(1, 1);
+      load_b(0);
+      __builtin_amdgcn_sched_barrier(0);
+      macs(1, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      return;
+    }
+#endif
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -375,28 +469,11 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh[nt], ah[mt], acc[mt][nt], 0, 0, 0);
 #else
-#ifdef EECT_MFMA_SHAPE_TIMING  // timing-only build (WRONG results): the same MACs on v_mfma_f32_16x16x32_bf16, two quarters of the accumulator
-          {
-            typedef float f32x4_t __attribute__((ext_vector_type(4)));
-            f32x16& c = acc[mt][nt];
-            f32x4_t q0 = {c[0], c[1], c[2], c[3]}, q2 = {c[8], c[9], c[10], c[11]};
-            if (NP == 3) {
-              q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], q0, 0, 0, 0);
-              q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mt], bh[nt], q2, 0, 0, 0);
-              q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], q0, 0, 0, 0);
-              q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bl[nt], q2, 0, 0, 0);
-            }
-            q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], q0, 0, 0, 0);
-            q2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mt], bh[nt], q2, 0, 0, 0);
-            c[0] = q0[0], c[1] = q0[1], c[2] = q0[2], c[3] = q0[3], c[8] = q2[0], c[9] = q2[1], c[10] = q2[2], c[11] = q2[3];
-          }
-#else
           if (NP == 3) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
           }
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-#endif
 #endif
         }
     }
@@ -474,6 +551,17 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   EECT_STAMP(1);
   if (fast) k_loop(FastTag<true>{});
   else k_loop(FastTag<false>{});
+#if EECT_MFMA16 && EECT_EPI_DIRECT != 2
+  // the k-loop kept the accumulators in the quadrant layout: back to the layout of the epilogues, once.  (The swaps are inline asm:
+  // the MFMA-result -> VALU-read hazard in front of them is padded by hand -- 19 wait states cover a 16-pass MFMA.)
+  if constexpr (kM16) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 2" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc_q_to_std(acc[i][j]);
+  }
+#endif
   EECT_STAMP(2);
   if constexpr (!AKC) {
     if (do_rs) {  // uniform over the workgroup.  The k-loop ended with a barrier: LDS is free.
