@@ -109,6 +109,19 @@ def launch_ranks(n, argv):
     return rc
 
 
+# The ONE JSON line goes to the process's original stdout; everything else that writes to file descriptor 1 -- RCCL's version
+# banner, gloo's connection notes, library chatter -- is sent to stderr (main() re-points fd 1 before any backend is initialised).
+_RECORD_OUT = sys.stdout
+
+
+def _isolate_stdout():
+    global _RECORD_OUT
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    _RECORD_OUT = os.fdopen(keep, "w")
+
+
 class RecordGuard:
     """Exactly ONE record per run, whatever happens in the last (training-step) section: the main thread emits it when the
     section is done; a rank that fails inside a step, or whose section does not finish in time (a hung collective), emits the
@@ -127,11 +140,12 @@ class RecordGuard:
             self._emitted = True
             if self.rank == 0 and self.line is not None:
                 self.line["train_step"] = train_obj
-                print(json.dumps(self.line), flush=True)
+                _RECORD_OUT.write(json.dumps(self.line) + "\n")
+                _RECORD_OUT.flush()
 
     def fail(self, msg, code):
         self.emit({"error": msg})
-        sys.stdout.flush()
+        _RECORD_OUT.flush()
         sys.stderr.write(f"bench.py: rank {self.rank}: {msg}\n")
         sys.stderr.flush()
         os._exit(code)
@@ -208,6 +222,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))  # launcher mode: no GPU call in this process
+    _isolate_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
