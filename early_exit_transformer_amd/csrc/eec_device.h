@@ -547,15 +547,14 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
             if (!SWAP) quad_mac16(acc[mt][nt], rb, wb, a, w);  // A = activations (row block rb), B = weights (row block wb)
             else quad_mac16(acc[mt][nt], wb, rb, w, a);        // A = weights, B = activations
           }
-      }
-      if (rb == 1) {
+        // this (row block, column tile) of the ring is finished: refill it right away -- the loads leave in pairs spread over the
+        // step instead of in one burst at its end (an in-order wave stalls at issue while the CU's load path is backed up)
+        if (rb == 1) {
 #ifdef EEC_ABLATE_W
-        if (false) {
+          if (false) {
 #else
-        if (2 * S + PF < KS) {
+          if (2 * S + PF < KS) {
 #endif
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
             r.q[(2 * S + wb) % PF][nt][0] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256];
 #ifdef EEC_X3_LO_SKIP
             if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = r.q[(2 * S + wb) % PF][nt][0];
