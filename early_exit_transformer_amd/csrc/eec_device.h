@@ -173,6 +173,18 @@ __device__ __forceinline__ hl2_t split2(float a, float b) {
   }
   return r;
 }
+// The same split as split2<3> (hi = rtz(x), lo = rtz(x - hi)) in 4 instructions instead of 6: v_fma_mix_f32 reads the fp16 halves
+// of `hi` directly (x - hi is exact in fp32 either way: identical results).
+__device__ __forceinline__ hl2_t split2_mix(float a, float b) {
+  hl2_t r;
+  const unsigned hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+  float la, lb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(la) : "v"(hi), "v"(a));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hi), "v"(b));
+  r.hi = __builtin_bit_cast(h2, hi);
+  r.lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(la, lb));
+  return r;
+}
 // SiLU in the exp2 domain: u = log2(e) * x  ->  u / (1 + 2^-u) = log2(e) * silu(x).
 // (log2(e) is folded into W1/b1 and 1/log2(e) into W2 at pack time.)  4 VALU, 2 transcendental.
 __device__ __forceinline__ float silu_exp2(float u) {

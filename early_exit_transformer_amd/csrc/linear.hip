@@ -263,12 +263,16 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
 #pragma unroll
       for (int j = 0; j < KB; ++j)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float p = __builtin_amdgcn_exp2f(sc[j][mt][i] - m_new);
-          psum += p;
-          const half_t ph = (half_t)p;
-          pf[j][i >> 3][i & 7] = ph;
-          if constexpr (X3) pfl[j][i >> 3][i & 7] = (half_t)(p - (float)ph);
+        for (int i = 0; i < 16; i += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(sc[j][mt][i] - m_new), p1 = __builtin_amdgcn_exp2f(sc[j][mt][i + 1] - m_new);
+          psum += p0 + p1;
+          if constexpr (X3) {  // hi / lo pair in 4 instructions (the softmax VALU, not the MFMAs, bounds this phase in the exact mode)
+            const hl2_t sp = split2_mix(p0, p1);
+            pf[j][i >> 3][i & 7] = sp.hi[0], pf[j][i >> 3][(i & 7) + 1] = sp.hi[1];
+            pfl[j][i >> 3][i & 7] = sp.lo[0], pfl[j][i >> 3][(i & 7) + 1] = sp.lo[1];
+          } else {
+            pf[j][i >> 3][i & 7] = (half_t)p0, pf[j][i >> 3][(i & 7) + 1] = (half_t)p1;
+          }
         }
       l_run[mt] = l_run[mt] * alpha + psum;
 #pragma unroll
