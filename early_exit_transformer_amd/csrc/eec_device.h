@@ -482,10 +482,43 @@ __device__ __forceinline__ const uint4* w_lane16(const uint4* w_lane) {
   return w_lane + 96 * hh + 16 * u;
 }
 
+// EEC_W_SADDR (experiment, off): the weight stream's loads as SGPR base + 32-bit lane offset (`global_load_dwordx4 v, v_off,
+// s[base:base+1]`) instead of a 64-bit address per lane -- half the address payload per load instruction.  Measured SLOWER: chain
+// launch 207.8 -> 217.6 us same-box (the uniform part has to be pinned in SGPRs per load with readfirstlane, or hipcc folds it back
+// into one 64-bit VGPR address): the ~75 cycles a fragment load costs its wave are not address traffic.
+#ifndef EEC_W_SADDR
+#define EEC_W_SADDR 0
+#endif
+struct WAddr16 {
+  const char* base;  // wave-uniform
+  unsigned voff;     // this lane's byte offset: slot (lane & 15) + 32 u of fragment hh
+  __device__ __forceinline__ uint4 load(size_t uniform_u4) const {
+#if EEC_W_SADDR
+    // the uniform part is pinned in SGPRs (readfirstlane is opaque to the optimiser: left alone it folds base + voff into ONE 64-bit
+    // VGPR address and adds the uniform offsets to that)
+    const size_t a = (size_t)base + uniform_u4 * 16;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return *(const uint4*)((const char*)(((size_t)hi << 32) | lo) + voff);
+#else
+    return *(const uint4*)(base + uniform_u4 * 16 + voff);
+#endif
+  }
+};
+__device__ __forceinline__ WAddr16 w_addr16(const uint4* w_lane) {
+  const int lane = lane_id(), hh = lane >> 5, u = (lane >> 4) & 1;
+#if EEC_W_SADDR
+  const uint4* b = w_lane - lane;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)b), hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)b >> 32));
+  return WAddr16{(const char*)(((size_t)hi << 32) | lo), (unsigned)(lane + 96 * hh + 16 * u) * 16u};
+#else
+  return WAddr16{(const char*)(w_lane + 96 * hh + 16 * u), 0u};
+#endif
+}
+
 template <int NP, int PF, int NT>
 __device__ __forceinline__ void ring_fill_16(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride, int steps_avail) {
   static_assert(PF % 2 == 0, "the ring is dealt in double k-steps");
-  const uint4* w16 = w_lane16(w_lane);
+  const WAddr16 w16 = w_addr16(w_lane);
 #ifdef EEC_ABLATE_W
   if (threadIdx.x > 100000)  // timing-only build: no weight loads at all
 #endif
@@ -494,8 +527,8 @@ __device__ __forceinline__ void ring_fill_16(WRing<NP, PF, NT>& r, const uint4* 
     if (p < steps_avail) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        r.q[p][nt][0] = w16[nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256];
-        if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = w16[nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256 + 64];
+        r.q[p][nt][0] = w16.load(nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256);
+        if (NP == 3) r.q[p][nt][(NP == 3) ? 1 : 0] = w16.load(nt * nt_stride + 16 * (p & 1) + (size_t)(p >> 1) * 256 + 64);
       }
     }
   __builtin_amdgcn_sched_barrier(0);  // keep these loads HERE: one stage ahead of their consumer
@@ -518,7 +551,7 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
   static_assert(KS % 2 == 0 && PF % 2 == 0, "double k-steps");
   constexpr int LO = (NP == 3) ? 1 : 0;
   const char* a16 = a_lane16(a_lane, ld_bytes);
-  const uint4* w16 = w_lane16(w_lane);
+  const WAddr16 w16 = w_addr16(w_lane);
   if constexpr (IN_STD) accs_std_to_q<MT, NT>(acc);
   h8 ah[2][MT], al[2][MT];  // [buffer][mt]: row block p & 1 of double step p >> 1
 #pragma unroll
@@ -567,11 +600,11 @@ __device__ __forceinline__ void gemm_ring_16(f32x16 (&acc)[MT][NT], const char* 
 #else
           if (2 * S + PF < KS) {
 #endif
-            r.q[(2 * S + wb) % PF][nt][0] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256];
+            r.q[(2 * S + wb) % PF][nt][0] = w16.load(nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256);
 #ifdef EEC_X3_LO_SKIP
             if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = r.q[(2 * S + wb) % PF][nt][0];
 #else
-            if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = w16[nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256 + 64];
+            if (NP == 3) r.q[(2 * S + wb) % PF][nt][LO] = w16.load(nt * nt_stride + 16 * wb + (size_t)(S + PF / 2) * 256 + 64);
 #endif
           }
         }
