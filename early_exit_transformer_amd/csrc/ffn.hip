@@ -69,6 +69,9 @@ template <int D> struct FfnPf<D, 8> { static constexpr int P1 = EEC_PF1_NP8, P2 
 #ifndef EEC_SIDE_VALU_NP8
 #define EEC_SIDE_VALU_NP8 5  // VALU instructions of the SiLU side work pinned behind each MFMA of GEMM1 (f8 stream)
 #endif
+#ifndef EEC_SIDE_VALU_NP3
+#define EEC_SIDE_VALU_NP3 3  // VALU instructions of the SiLU side work pinned behind each MFMA pair of GEMM1 (split format)
+#endif
 #ifndef EEC_NW1
 #define EEC_NW1 4
 #endif
@@ -499,7 +502,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
               gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(
                   cur, a_lane, kALd, a8_lane, kA8Ld, w1f8_lane(W, ft), 0, r1, wg1, side);
             else
-              gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? 3 : 7), MT, !Q16, !Q16>(cur, a_lane, kALd, kAPlane, w1_lane,
+              gemm_ring<RNP, KS, 1, true, kPF1, decltype(side), (NP == 3 ? EEC_SIDE_VALU_NP3 : 7), MT, !Q16, !Q16>(cur, a_lane, kALd, kAPlane, w1_lane,
                                                                                                   0, r1, side);
           } else {
             if constexpr (NP == 8)

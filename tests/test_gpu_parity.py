@@ -225,6 +225,10 @@ def test_fused_plan_equals_substep_plan(prec):
     (2, 1100, [1100, 640]),          # T' = 274 > 256: two key chunks in the attention kernel
     (3, 259, [259, 259, 259]),       # no padding at all
     (4, 61, [1, 8, 61, 3]),          # lengths < 4 -> encoder length 0: every key masked (torch's safe softmax: zeros)
+    # T' a multiple of 64: the attention runs inside the out_proj / GLU launch (capi.hip attn_fusable)
+    (4, 515, [515, 300, 9, 2]),      # T' = 128, keys masked mid-tile, one utterance of encoder length 0
+    (2, 771, [771, 400]),            # T' = 192: three row tiles per utterance
+    (2, 1283, [1283, 1000]),         # T' = 320 > 256: two key chunks, the second a quarter full
 ])
 def test_ragged_shapes(B, T, lens):
     kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=256)
