@@ -967,7 +967,8 @@ __device__ __forceinline__ RowV<Q> zero_row() {
 // LayerNorm of N rows (row = D columns over 64 lanes).  The reductions of the N rows run as N independent,
 // interleaved DPP chains.
 template <int D, int N>
-__device__ __forceinline__ void layer_norm_rows(RowV<Geo<D>::kQ> (&v)[N], const RowV<Geo<D>::kQ>& g, const RowV<Geo<D>::kQ>& bt) {
+__device__ __forceinline__ void layer_norm_rows(RowV<Geo<D>::kQ> (&v)[N], const RowV<Geo<D>::kQ>& g, const RowV<Geo<D>::kQ>& bt,
+                                                float* mean_out = nullptr, float* rstd_out = nullptr) {  // optional: the N rows' statistics
   constexpr int Q = Geo<D>::kQ;
   float s[N];
 #pragma unroll
@@ -981,6 +982,7 @@ __device__ __forceinline__ void layer_norm_rows(RowV<Geo<D>::kQ> (&v)[N], const 
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const float mean = s[i] * (1.0f / D);
+    if (mean_out) mean_out[i] = mean;
     sq[i] = 0.f;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -993,6 +995,7 @@ __device__ __forceinline__ void layer_norm_rows(RowV<Geo<D>::kQ> (&v)[N], const 
 #pragma unroll
   for (int i = 0; i < N; ++i) {
     const float rs = rsqrtf(sq[i] * (1.0f / D) + kLnEps);
+    if (rstd_out) rstd_out[i] = rs;
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       float4& t = v[i].p[q];

@@ -126,6 +126,16 @@ struct FfnStage {
   float res_scale;
   float* tap;                  // optional [M][256]: the stage's output rows are stored here too (exit taps)
 };
+// Training-step extras of a single-stage chain launch (the TR variants of ffn_chain_kernel; train.hip ffn_fwd): what the backward
+// needs is recorded on the way, the two dropout sites of the module are applied with the training step's generator (eec_drop.h)
+struct ChainTrain {
+  float* y;                 // [M][D] output rows (x is only read)
+  float *ln, *mean, *rstd;  // [M][D], [M], [M]: LayerNorm output and statistics of the input rows
+  float *pre, *act;         // [M][F]: W1 . LN(x) + b1, and drop(silu(pre))
+  float p;                  // dropout probability (0: no dropout)
+  unsigned long long seed;
+  unsigned site_act, site_res;
+};
 struct ChainArgs {
   float* x;  // [M][D] residual stream, updated in place
   int M, F, nstage, D;
@@ -134,7 +144,11 @@ struct ChainArgs {
   QkvArgs qkv;      // tail (x / M of this block are ignored)
   DwArgs dw;        // front
   ProjResArgs pw2;  // front (a_hi / a_lo unused)
+  ChainTrain tr;    // TR variants only
 };
+// the feed-forward module of the training step's forward as one launch (plain-domain SiLU, weights packed with scale 1);
+// np 3 or 1; d_model 256 / 512, F % 32 == 0
+hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st);
 hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st);
 
 struct SubsampleArgs {

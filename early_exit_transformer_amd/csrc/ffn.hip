@@ -28,6 +28,7 @@
 // Executed MFMA work is NP x that.  HBM/L2 traffic per launch: x read+write 2 KiB/row; each
 // workgroup streams all 2*D*F*2 B (x2 planes when NP=3) of weights once from L2.
 #include "eec_blocks.h"
+#include "eec_drop.h"
 
 namespace eec {
 
@@ -226,11 +227,18 @@ __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, flo
 //   FNP  0: stage 0 reads x;  else: the depthwise + pointwise-2 front (format FNP) produces x first
 //   QNP  0: none;  else: the attention in_proj of the NEXT half-layer (format QNP) runs on the final rows
 //   NS   number of FFN stages (1 or 2)
-template <int D, int NP, int ACT, int FNP, int QNP, int NS>
+//   TR   the feed-forward module of the TRAINING step's forward (train.hip ffn_fwd; train.py:54 in train mode): one stage, no front
+//        or tail, ACT = 2 (SiLU in the plain domain: the weights are this step's parameters, packed with scale 1), dropout after
+//        the activation and on the module's output (a.tr sites), output rows to a.tr.y, and everything the backward reads --
+//        LN(x) and its statistics, W1 . LN(x) + b1, drop(silu(.)) -- recorded on the way: the [M, F] tensors are written once
+//        and never read back by the forward
+template <int D, int NP, int ACT, int FNP, int QNP, int NS, bool TR = false>
 #ifndef EEC_FFN_MINWAVES
 #define EEC_FFN_MINWAVES 2
 #endif
 __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kernel(ChainArgs a) {
+  static_assert(!TR || (FNP == 0 && QNP == 0 && NS == 1 && ACT == 2 && NP != 8), "TR: one plain stage");
+  static_assert(TR || ACT != 2, "ACT = 2 is the training variant's");
   using G = Geo<D>;
   using FG = FfnGeo<D>;
   constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS, RPW = G::kRPW, NT2 = FG::kNT2;
@@ -313,6 +321,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
   // (with the split inside the loop the register allocator keeps both roles' state live: ~600 spilled VGPRs).
   auto run = [&](auto prod_tag) {
   constexpr bool producer = decltype(prod_tag)::value;
+  [[maybe_unused]] const eect::DropState ds_act(eect::Drop{TR ? a.tr.p : 0.0f, a.tr.seed, a.tr.site_act});
   WRing<RNP, kPF1, 1> r1;
   WRing<RNP, kPF2, NTP> r2;
   WGroupF8<1> wg1[kNW1];    // NP == 8: lo8 + scales of GEMM1 (K = D = D/64 groups), rolling through kNW1 buffers
@@ -397,7 +406,31 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
   } else {
     const WPtrs W0 = wptrs(0);
-    rows_f32_to_planes<D, NP, true>(smem, x, row0, M, a.st[0].ln_g, a.st[0].ln_b, [&]() { start_streams(W0); });
+    if constexpr (TR) {  // as rows_f32_to_planes, and the LayerNormed rows and their statistics go to the tape
+      const RowV<G::kQ> lg = load_row<D>(a.st[0].ln_g, lane), lb = load_row<D>(a.st[0].ln_b, lane);
+      RowV<G::kQ> v[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w * RPW + i;
+        v[i] = zero_row<G::kQ>();
+        if (row < M) v[i] = load_row<D>(x + (size_t)row * D, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      start_streams(W0);
+      float mu[RPW], rs[RPW];
+      layer_norm_rows<D, RPW>(v, lg, lb, mu, rs);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w * RPW + i;
+        if (row < M) {
+          store_row<D>(a.tr.ln + (size_t)row * D, v[i], lane);
+          if (lane == 0) a.tr.mean[row] = mu[i], a.tr.rstd[row] = rs[i];
+        }
+      }
+      rows_to_planes<D, NP, RPW>(smem, v, w * RPW, row0, M, true);
+    } else {
+      rows_f32_to_planes<D, NP, true>(smem, x, row0, M, a.st[0].ln_g, a.st[0].ln_b, [&]() { start_streams(W0); });
+    }
   }
   TL_STAMP();  // 1: prologue done
   __syncthreads();
@@ -420,9 +453,40 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
       // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator.  Standard layout: register quad
       // g = q >> 1 of lane (hh, r32) is hidden units 8 g + 4 hh .. + 3 of frame r32.  Quadrant layout (Q16): quad g = 2 ra + cb is
       // hidden units 16 ra + 8 hh + 4 u .. + 3 of frame 16 cb + (lane & 15) -- either way four consecutive halves of one H row.
-      auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo) {
+      auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo, [[maybe_unused]] int hcol0 = 0) {
         const int mt = step >> 3, q = step & 7;
         const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
+        if constexpr (TR) {
+          // even q: the two SiLU values wait in (keep_hi, keep_lo) as floats; odd q: the quad's four pre-activations and its four
+          // dropped activations go to the tape (one float4 each: the (hh, u) lanes of a frame cover 64 contiguous bytes), and the
+          // dropped activations, split, into the H tile
+          const float s0 = silu_f(u0), s1 = silu_f(u1);
+          if ((q & 1) == 0) {
+            keep_hi = __builtin_bit_cast(h2, s0);
+            keep_lo = __builtin_bit_cast(h2, s1);
+            return;
+          }
+          const int g = q >> 1;
+          const int frame = Q16 ? mt * 32 + 16 * (g & 1) + (lane & 15) : mt * 32 + (lane & 31);
+          const int hid = Q16 ? wl * 32 + 16 * (g >> 1) + 8 * hh + 4 * ((lane >> 4) & 1) : wl * 32 + 4 * hh + g * 8;
+          const int row = row0 + frame;
+          const size_t idx = (size_t)row * F + hcol0 + hid;
+          float m[4];
+          ds_act.mul4(idx, m);
+          const float h0 = __builtin_bit_cast(float, keep_hi) * m[0], h1 = __builtin_bit_cast(float, keep_lo) * m[1], h2v = s0 * m[2], h3 = s1 * m[3];
+          if (row < M) {
+            *(float4*)(a.tr.pre + idx) = make_float4(acc[mt][0][2 * q - 2], acc[mt][0][2 * q - 1], u0, u1);
+            *(float4*)(a.tr.act + idx) = make_float4(h0, h1, h2v, h3);
+          }
+          constexpr int SNPT = NP == 1 ? 1 : 3;
+          const hl2_t sa = split2<SNPT>(h0, h1), sb = split2<SNPT>(h2v, h3);
+          char* dst = hb + frame * kHLd + hid * 2;
+          h4 hi, lo;
+          hi.xy = sa.hi, hi.zw = sb.hi, lo.xy = sa.lo, lo.zw = sb.lo;
+          *(h4*)dst = hi;
+          if (NP == 3) *(h4*)(dst + kHPlane) = lo;
+          return;
+        }
 #ifdef EEC_ABLATE_SILU  // timing-only build: no activation work at all (H stays uninitialised)
         asm volatile("" ::"v"(u0), "v"(u1));
         (void)hb, (void)keep_hi, (void)keep_lo;
@@ -489,6 +553,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
         const bool do_gemm = s < nchunk && ft < nft;
         const bool do_silu = s >= 1 && s - 1 < nchunk && phys(s - 1) * 4 + wl < nft;
         char* hb_prev = lds_h + ((s - 1) & 1) * 2 * kHPlane;
+        [[maybe_unused]] const int hcol_prev = do_silu ? phys(s - 1) * kFC : 0;  // TR: hidden column of the chunk being activated
         h2 khi, klo;
         if (do_gemm) {
           init_bias(cur, ft);
@@ -496,7 +561,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
           const char* a8_lane = smem + kAPlane + (lane & 31) * kA8Ld + hh * 32;
           if (do_silu) {
             auto side = [&](int st) {
-              if (st % kSideEvery == 0) silu_pair(prev, hb_prev, st / kSideEvery, khi, klo);
+              if (st % kSideEvery == 0) silu_pair(prev, hb_prev, st / kSideEvery, khi, klo, hcol_prev);
             };
             if constexpr (NP == 8)
               gemm_ring_f8<D / 64, 1, true, kPF1, decltype(side), EEC_SIDE_VALU_NP8, kNW1, EEC_DROP1, MT, false, (EEC_X_HI8 ? G::kA8Hi : 0)>(
@@ -514,7 +579,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
           if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(W, phys(s + 1) * 4 + wl);  // next chunk's W1 stream
         } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
 #pragma unroll
-          for (int st = 0; st < 8 * MT; ++st) silu_pair(prev, hb_prev, st, khi, klo);
+          for (int st = 0; st < 8 * MT; ++st) silu_pair(prev, hb_prev, st, khi, klo, hcol_prev);
         }
         TL_STAMP();  // producer: slot work done
         __syncthreads();
@@ -635,7 +700,26 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     const float res_scale = EEC_STAGE_FIELD(si, res_scale);
     const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
     float* tap = EEC_STAGE_FIELD(si, tap);
-    if constexpr (more) {  // only stage 0 can have a successor
+    if constexpr (TR) {
+      // y = x + res_scale * drop(W2 . h + b2): the row pass with the output dropout of the module, rows to a.tr.y
+      const eect::DropState ds_res(eect::Drop{a.tr.p, a.tr.seed, a.tr.site_res});
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w_e * RPW + i;
+        RowV<G::kQ> v = xr[i];
+#pragma unroll
+        for (int q = 0; q < G::kQ; ++q) {
+          const float4 e = *(const float4*)(lds_e + (w_e * RPW + i) * G::kELd + (q * 256 + lane_e * 4) * 4);
+          float m[4];
+          ds_res.mul4((size_t)row * D + q * 256 + lane_e * 4, m);
+          v.p[q].x += res_scale * m[0] * e.x;
+          v.p[q].y += res_scale * m[1] * e.y;
+          v.p[q].z += res_scale * m[2] * e.z;
+          v.p[q].w += res_scale * m[3] * e.w;
+        }
+        if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v, lane_e);
+      }
+    } else if constexpr (more) {  // only stage 0 can have a successor
       chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b, lane_e, w_e);
     } else if constexpr (QNP != 0) {
       chain_rowpass<D, QNP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.qkv.ln_g, a.qkv.ln_b, lane_e, w_e);
@@ -675,9 +759,9 @@ extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
 }
 #endif
 
-template <int D, int NP, int ACT, int FNP, int QNP, int NS>
+template <int D, int NP, int ACT, int FNP, int QNP, int NS, bool TR = false>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
-  auto k = ffn_chain_kernel<D, NP, ACT, FNP, QNP, NS>;
+  auto k = ffn_chain_kernel<D, NP, ACT, FNP, QNP, NS, TR>;
   constexpr int lds = FNP != 0 ? (DwGeo<D>::kLds > FfnGeo<D>::kLds ? DwGeo<D>::kLds : FfnGeo<D>::kLds) : FfnGeo<D>::kLds;
   if (hipError_t e = ensure_max_lds((const void*)k, lds); e != hipSuccess) return e;
   const int grid = (a.M + Geo<D>::kRows - 1) / Geo<D>::kRows;
@@ -685,6 +769,17 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
+#ifdef EEC_FFN_TRAIN
+// Third object of this source (build/ffn_train.o): only the training variants.
+hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st) {
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
+  if (!a.tr.y || !a.tr.ln || !a.tr.mean || !a.tr.rstd || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
+  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, true>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, true>(a, st);
+  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, true>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, true>(a, st);
+  return hipErrorInvalidValue;
+}
+}  // namespace eec
+#else
 // This file is compiled once per d_model (-DEEC_FFN_D=256 / 512: two objects, so the two sets of chain-kernel variants
 // build in parallel); each object defines launch_ffn_chain_d<EEC_FFN_D>, the D = 256 object also the dispatchers.
 #ifndef EEC_FFN_D
@@ -755,3 +850,4 @@ hipError_t launch_ffn(const FfnArgs& f, int np, hipStream_t st) {
 #endif
 
 }  // namespace eec
+#endif  // EEC_FFN_TRAIN

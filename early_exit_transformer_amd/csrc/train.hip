@@ -191,11 +191,35 @@ void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const floa
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------------------
+// the feed-forward module as one launch (a property of the configuration: the sizing pass carves the same way);
+// EEC_TRAIN_FFN_FUSED=0 keeps the LayerNorm + two-GEMM path (A/B runs, and what other geometries take)
+bool ffn_fused_fwd_supported(const eec_trainer* tr) {
+  static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED"); return e && atoi(e) == 0; }();
+  const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
+}
 float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.pre = r.tape.f((size_t)M * F);
   t.act = r.tape.f((size_t)M * F);
   t.site_act = r.site++, t.site_res = r.site++;
+  if (ffn_fused_fwd_supported(r.tr)) {
+    // ONE launch (ffn.hip, TR variants of the chain kernel): LayerNorm, both GEMMs, SiLU, both dropout sites and the residual; the
+    // [M, F] tensors are written to the tape from the accumulators and never read back by the forward.  Its GEMMs run on split
+    // fp16 fragments of THIS step's parameters: packed here, 2 x 2 MB per module.
+    r.scr.reset();
+    float* w1p = r.scr.f((size_t)F * D);
+    float* w2p = r.scr.f((size_t)D * F);
+    float* y = r.tape.f((size_t)M * D);
+    RUN(eec::launch_pack_frags(w1, F, D, (uint4*)w1p, 1.0f, r.st));
+    RUN(eec::launch_pack_frags(w2, D, F, (uint4*)w2p, 1.0f, r.st));
+    eec::ChainArgs a{};
+    a.x = x, a.M = M, a.F = F, a.nstage = 1, a.D = D;
+    a.st[0] = eec::FfnStage{ln_w, ln_b, (const uint4*)w1p, b1, (const uint4*)w2p, b2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
+    a.tr = eec::ChainTrain{y, t.ln, t.mean, t.rstd, t.pre, t.act, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    RUN(eec::launch_ffn_train_fwd(a, r.tr->np, r.st));
+    return y;
+  }
   RUN(launch_ln_fwd(x, ln_w, ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
   {  // pre = LN(x) . W1^T + b1 and, in the same epilogue, act = drop(silu(pre))
     GemmArgs g = gemm_args(t.ln, D, 1, w1, D, 1, t.pre, F, M, F, D);
