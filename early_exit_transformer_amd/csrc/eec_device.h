@@ -39,6 +39,16 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// EEC_OPERAND_BF16 (a translation-unit switch; only the training step's fused feed-forward BACKWARD sets it, ffn.hip): the split
+// operands are bf16 hi / lo pairs (2^-16 per product, the fp32 exponent range: gradients) on v_mfma_*_bf16 instead of fp16 pairs.
+// Fragments keep their h8 / h2 storage types -- only the conversions and the MFMA builtins differ.
+#ifndef EEC_OPERAND_BF16
+#define EEC_OPERAND_BF16 0
+#endif
+typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
 constexpr int kWave = 64;
 constexpr float kLnEps = 1e-5f;
 constexpr float kLog2e = 1.4426950408889634f;
@@ -163,6 +173,15 @@ struct hl2_t {
 template <int NP>
 __device__ __forceinline__ hl2_t split2(float a, float b) {
   hl2_t r;
+#if EEC_OPERAND_BF16
+  {
+    const f32x2_t x = {a, b};
+    const bf2_t hi = __builtin_convertvector(x, bf2_t);
+    r.hi = __builtin_bit_cast(h2, hi);
+    r.lo = NP == 3 ? __builtin_bit_cast(h2, __builtin_convertvector(x - __builtin_convertvector(hi, f32x2_t), bf2_t)) : r.hi;
+    return r;
+  }
+#endif
   if (NP == 3) {
     r.hi = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a, b));
     r.lo = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a - (float)r.hi[0], b - (float)r.hi[1]));
@@ -194,7 +213,11 @@ __device__ __forceinline__ float silu_exp2(float u) {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x)); }
 
 __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+#if EEC_OPERAND_BF16
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
 }
 // row of accumulator register i for this lane (within a 32x32 tile)
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
@@ -418,7 +441,13 @@ __device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][NT], const char
 #define EEC_MFMA16 1
 #endif
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
+#if EEC_OPERAND_BF16
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8_t, a), __builtin_bit_cast(bf8_t, b), c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
+}
 // quadrant (ra, cb) of a tile += A[ra] . B[cb]^T for ra, cb in {0, 1}
 __device__ __forceinline__ void tile_mac16(f32x16& acc, const h8 (&a)[2], const h8 (&b)[2]) {
 #pragma unroll

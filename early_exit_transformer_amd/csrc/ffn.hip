@@ -27,6 +27,9 @@
 // Algorithmic work: 4*D*F flop per row (2.097 MFLOP at D=256, F=2048); bound: MFMA.
 // Executed MFMA work is NP x that.  HBM/L2 traffic per launch: x read+write 2 KiB/row; each
 // workgroup streams all 2*D*F*2 B (x2 planes when NP=3) of weights once from L2.
+#ifdef EEC_FFN_TRAIN_BWD  // fourth object of this source: the backward variants, on bf16 operands (see eec_device.h)
+#define EEC_OPERAND_BF16 1
+#endif
 #include "eec_blocks.h"
 #include "eec_drop.h"
 
@@ -44,9 +47,25 @@ struct FfnGeo {
   // (D = 256: it fits inside them; D = 512: it is the larger of the two)
   static constexpr int kLds = 2 * G::kAPlane + (4 * kHPlane > G::kETile ? 4 * kHPlane : G::kETile);  // 137216 / 132608
 };
+#ifndef EEC_TR_ABLATE
+#define EEC_TR_ABLATE 0
+#endif
+#ifndef EEC_TR_NT
+#define EEC_TR_NT 1  // TR variants: tape stores with the non-temporal hint
+#endif
+#ifndef EEC_TR_BURST
+#define EEC_TR_BURST 0  // TR variants: 1 = tape stores of a chunk in one burst before the slot's barrier (measured slower: 136-139 against 125.5 us)
+#endif
 // k-steps of W1 / W2 fragments a producer / consumer wave keeps in flight.  The shared weight stream
 // out of L2 is latency x concurrency bound (tools/l2bw.hip: 64 KiB in flight per CU -> 18 TB/s,
 // 128 KiB -> 28 TB/s), so the rings are as deep as the register budget allows.
+#if (defined(EEC_FFN_TRAIN_BWD) || (defined(EEC_FFN_TRAIN) && EEC_TR_BURST)) && !defined(EEC_PF1_NP3)
+// these variants' producers hold 32 more values across a slot (backward: the requested pre-activations): paid for with two k-steps of the ring
+#define EEC_PF1_NP3 6
+#define EEC_PF2_NP3 (EEC_MFMA16 ? 2 : 4)
+#define EEC_PF1_NP1 12
+#define EEC_PF2_NP1 8
+#endif
 #ifndef EEC_PF1_NP3
 #define EEC_PF1_NP3 8
 // (4 with the 32x32x16 k-loops; the 16x16x32 consumer loop of the split format needs a few registers more, and with four steps
@@ -164,6 +183,18 @@ __device__ __forceinline__ unsigned touch_chunk(const uint4* w1f8, const uint4* 
   return *(const unsigned*)p;
 #endif
 }
+// 16-byte store to the training tape.  Non-temporal: 268 MB of [M, F] tensors per launch written through the L2 as ordinary lines push
+// the weight stream -- 6.5 MB per stage against 4 MB of L2 per XCD -- out of it (same-box A/B: 172.6 us per launch with plain stores,
+// 135.4 us with the hint, 99.7 us without any tape stores; profiles/r04_micro_ffn_train_fwd.txt)
+__device__ __forceinline__ void tape_store4(float* p, float x, float y, float z, float w) {
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  const f32x4_t v = {x, y, z, w};
+#if EEC_TR_NT
+  __builtin_nontemporal_store(v, (f32x4_t*)p);
+#else
+  *(f32x4_t*)p = v;
+#endif
+}
 // f(IntTag<0>{}), ..., f(IntTag<N-1>{}) for N <= 2: a stage loop whose index is a compile-time constant
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -231,14 +262,19 @@ __device__ __forceinline__ void chain_rowpass(char* smem, const char* lds_e, flo
 //        or tail, ACT = 2 (SiLU in the plain domain: the weights are this step's parameters, packed with scale 1), dropout after
 //        the activation and on the module's output (a.tr sites), output rows to a.tr.y, and everything the backward reads --
 //        LN(x) and its statistics, W1 . LN(x) + b1, drop(silu(.)) -- recorded on the way: the [M, F] tensors are written once
-//        and never read back by the forward
-template <int D, int NP, int ACT, int FNP, int QNP, int NS, bool TR = false>
+//        and never read back by the forward.
+//        TR = 2: the data path of that module's BACKWARD with the same machinery (x = dh, W1 slot = W2^T, W2 slot = W1^T, bf16 operands):
+//        GEMM1 gives dh . W2 per chunk, the activation step is * mask * silu'(pre) with `pre` read back from the tape (requested one
+//        slot ahead) and the result d(pre) stored for the weight-gradient GEMM, GEMM2 accumulates d(pre) . W1 = d(LN(x)); no LayerNorm,
+//        bias, residual or output dropout
+template <int D, int NP, int ACT, int FNP, int QNP, int NS, int TR = 0>
 #ifndef EEC_FFN_MINWAVES
 #define EEC_FFN_MINWAVES 2
 #endif
 __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kernel(ChainArgs a) {
   static_assert(!TR || (FNP == 0 && QNP == 0 && NS == 1 && ACT == 2 && NP != 8), "TR: one plain stage");
   static_assert(TR || ACT != 2, "ACT = 2 is the training variant's");
+  static_assert((TR == 2) == (EEC_OPERAND_BF16 != 0), "the backward variant (and only it) runs on bf16 operands");
   using G = Geo<D>;
   using FG = FfnGeo<D>;
   constexpr int MT = G::kMT, NW = G::kNW, KS = G::kKS, RPW = G::kRPW, NT2 = FG::kNT2;
@@ -406,7 +442,9 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, 1.0f, nullptr, nullptr, nullptr, a.st[0].ln_g, a.st[0].ln_b);
   } else {
     const WPtrs W0 = wptrs(0);
-    if constexpr (TR) {  // as rows_f32_to_planes, and the LayerNormed rows and their statistics go to the tape
+    if constexpr (TR == 2) {
+      rows_f32_to_planes<D, NP, false>(smem, x, row0, M, nullptr, nullptr, [&]() { start_streams(W0); });
+    } else if constexpr (TR == 1) {  // as rows_f32_to_planes, and the LayerNormed rows and their statistics go to the tape
       const RowV<G::kQ> lg = load_row<D>(a.st[0].ln_g, lane), lb = load_row<D>(a.st[0].ln_b, lane);
       RowV<G::kQ> v[RPW];
 #pragma unroll
@@ -453,10 +491,56 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
       // SiLU + hi/lo split + ds_write of values [2q, 2q+1] of tile mt of a finished accumulator.  Standard layout: register quad
       // g = q >> 1 of lane (hh, r32) is hidden units 8 g + 4 hh .. + 3 of frame r32.  Quadrant layout (Q16): quad g = 2 ra + cb is
       // hidden units 16 ra + 8 hh + 4 u .. + 3 of frame 16 cb + (lane & 15) -- either way four consecutive halves of one H row.
+      // TR: the dropped activations of the chunk being activated, kept for the burst of tape stores at the end of the slot
+      [[maybe_unused]] f32x16 hq[TR == 1 && EEC_TR_BURST ? MT : 1];
+      // TR = 2: the pre-activations of the chunk this wave multiplied last, in the accumulator's element order
+      [[maybe_unused]] f32x16 preq[TR == 2 ? MT : 1];
+      [[maybe_unused]] auto request_pre = [&](int hcol0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int frame = Q16 ? mt * 32 + 16 * (g & 1) + (lane & 15) : mt * 32 + (lane & 31);
+            const int hid = Q16 ? wl * 32 + 16 * (g >> 1) + 8 * hh + 4 * ((lane >> 4) & 1) : wl * 32 + 4 * hh + g * 8;
+            const int row = min(row0 + frame, M - 1);  // clamped, not branched: rows past the end are never stored
+            typedef float f32x4_t __attribute__((ext_vector_type(4)));
+            const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)(a.tr.pre + (size_t)row * F + hcol0 + hid));
+            preq[mt][4 * g] = v[0], preq[mt][4 * g + 1] = v[1], preq[mt][4 * g + 2] = v[2], preq[mt][4 * g + 3] = v[3];
+          }
+      };
       auto silu_pair = [&](const f32x16 (&acc)[MT][1], char* hb, int step, h2& keep_hi, h2& keep_lo, [[maybe_unused]] int hcol0 = 0) {
         const int mt = step >> 3, q = step & 7;
         const float u0 = acc[mt][0][2 * q], u1 = acc[mt][0][2 * q + 1];
-        if constexpr (TR) {
+        if constexpr (TR == 2) {
+          // u0, u1 are (dh . W2) of two hidden units; their pre-activations wait in preq (requested at the end of the previous slot)
+          const float x0 = preq[mt][2 * q], x1 = preq[mt][2 * q + 1];
+          const float sg0 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x0));
+          const float sg1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * x1));
+          const float t0 = u0 * sg0 * (1.0f + x0 * (1.0f - sg0)), t1 = u1 * sg1 * (1.0f + x1 * (1.0f - sg1));
+          if ((q & 1) == 0) {
+            keep_hi = __builtin_bit_cast(h2, t0);
+            keep_lo = __builtin_bit_cast(h2, t1);
+            return;
+          }
+          const int g = q >> 1;
+          const int frame = Q16 ? mt * 32 + 16 * (g & 1) + (lane & 15) : mt * 32 + (lane & 31);
+          const int hid = Q16 ? wl * 32 + 16 * (g >> 1) + 8 * hh + 4 * ((lane >> 4) & 1) : wl * 32 + 4 * hh + g * 8;
+          const int row = row0 + frame;
+          const size_t idx = (size_t)row * F + hcol0 + hid;
+          float m[4];
+          ds_act.mul4(idx, m);
+          const float d0 = __builtin_bit_cast(float, keep_hi) * m[0], d1 = __builtin_bit_cast(float, keep_lo) * m[1], d2 = t0 * m[2], d3 = t1 * m[3];
+          if (row < M) tape_store4(a.tr.act + idx, d0, d1, d2, d3);
+          constexpr int SNPT = NP == 1 ? 1 : 3;
+          const hl2_t sa = split2<SNPT>(d0, d1), sb = split2<SNPT>(d2, d3);
+          char* dst = hb + frame * kHLd + hid * 2;
+          h4 hi, lo;
+          hi.xy = sa.hi, hi.zw = sb.hi, lo.xy = sa.lo, lo.zw = sb.lo;
+          *(h4*)dst = hi;
+          if (NP == 3) *(h4*)(dst + kHPlane) = lo;
+          return;
+        }
+        if constexpr (TR == 1) {
           // even q: the two SiLU values wait in (keep_hi, keep_lo) as floats; odd q: the quad's four pre-activations and its four
           // dropped activations go to the tape (one float4 each: the (hh, u) lanes of a frame cover 64 contiguous bytes), and the
           // dropped activations, split, into the H tile
@@ -472,12 +556,20 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
           const int row = row0 + frame;
           const size_t idx = (size_t)row * F + hcol0 + hid;
           float m[4];
+#if EEC_TR_ABLATE & 2  // timing-only builds (tools/ffn_train_bench.hip): no mask / no tape stores
+          m[0] = m[1] = m[2] = m[3] = 1.0f;
+#else
           ds_act.mul4(idx, m);
+#endif
           const float h0 = __builtin_bit_cast(float, keep_hi) * m[0], h1 = __builtin_bit_cast(float, keep_lo) * m[1], h2v = s0 * m[2], h3 = s1 * m[3];
-          if (row < M) {
-            *(float4*)(a.tr.pre + idx) = make_float4(acc[mt][0][2 * q - 2], acc[mt][0][2 * q - 1], u0, u1);
-            *(float4*)(a.tr.act + idx) = make_float4(h0, h1, h2v, h3);
+#if EEC_TR_BURST
+          hq[mt][4 * g + 0] = h0, hq[mt][4 * g + 1] = h1, hq[mt][4 * g + 2] = h2v, hq[mt][4 * g + 3] = h3;
+#else
+          if (row < M && !(EEC_TR_ABLATE & 1)) {
+            tape_store4(a.tr.pre + idx, acc[mt][0][2 * q - 2], acc[mt][0][2 * q - 1], u0, u1);
+            tape_store4(a.tr.act + idx, h0, h1, h2v, h3);
           }
+#endif
           constexpr int SNPT = NP == 1 ? 1 : 3;
           const hl2_t sa = split2<SNPT>(h0, h1), sb = split2<SNPT>(h2v, h3);
           char* dst = hb + frame * kHLd + hid * 2;
@@ -515,7 +607,36 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
           }
         }
       };
+      // TR: the tape stores of a chunk (pre-activations from `acc`, dropped activations from hq) as ONE burst at the end of the slot.
+      // vmcnt retires in issue order, loads and stores alike: a store between two ring loads makes the wait for the second load a wait for
+      // the store's acknowledgement too (stores in the k-loop: 157 us per launch against 102 us without any; tools/ffn_train_bench.hip).
+      // Issued together right before the slot's barrier, they are acknowledged while the wave waits there.
+      [[maybe_unused]] auto tape_burst = [&](const f32x16 (&acc)[MT][1], int hcol0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int frame = Q16 ? mt * 32 + 16 * (g & 1) + (lane & 15) : mt * 32 + (lane & 31);
+            const int hid = Q16 ? wl * 32 + 16 * (g >> 1) + 8 * hh + 4 * ((lane >> 4) & 1) : wl * 32 + 4 * hh + g * 8;
+#if EEC_TR_ABLATE & 8  // timing-only: the same bytes as whole 128-byte lines per instruction (8 frames x 128 B; values land in the wrong places)
+            const int c16 = lane & 15;
+            const int row = row0 + mt * 32 + 16 * (g & 1) + (c16 & 7) + 8 * (g >> 1);
+            const size_t idx = (size_t)row * F + hcol0 + wl * 32 + 16 * (c16 >> 3) + 8 * hh + 4 * ((lane >> 4) & 1);
+#else
+            const int row = row0 + frame;
+            const size_t idx = (size_t)row * F + hcol0 + hid;
+#endif
+            if (row < M && !(EEC_TR_ABLATE & 1)) {
+              tape_store4(a.tr.pre + idx, acc[mt][0][4 * g], acc[mt][0][4 * g + 1], acc[mt][0][4 * g + 2], acc[mt][0][4 * g + 3]);
+              tape_store4(a.tr.act + idx, hq[mt][4 * g], hq[mt][4 * g + 1], hq[mt][4 * g + 2], hq[mt][4 * g + 3]);
+            }
+          }
+      };
       auto init_bias = [&](f32x16 (&acc)[MT][1], int ft) {
+        if constexpr (TR == 2) {
+          zero_acc(acc);
+          return;
+        }
         if constexpr (Q16) {  // quadrant layout: register 4 (2 ra + cb) + i <-> hidden unit 16 ra + 8 hh + 4 u + i
           const int u = (lane >> 4) & 1;
 #pragma unroll
@@ -577,9 +698,13 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
               gemm_ring<RNP, KS, 1, true, kPF1, NoSide, 0, MT, !Q16, !Q16>(cur, a_lane, kALd, kAPlane, w1_lane, 0, r1);
           }
           if (s + 1 < nchunk && phys(s + 1) * 4 + wl < nft) fill1(W, phys(s + 1) * 4 + wl);  // next chunk's W1 stream
+          if constexpr (TR == 2) request_pre(phys(s) * kFC);  // consumed by the next slot's side work
         } else if (do_silu) {  // the last chunk's SiLU has no GEMM1 to hide under
 #pragma unroll
           for (int st = 0; st < 8 * MT; ++st) silu_pair(prev, hb_prev, st, khi, klo, hcol_prev);
+        }
+        if constexpr (TR == 1 && EEC_TR_BURST) {
+          if (do_silu) tape_burst(prev, hcol_prev);
         }
         TL_STAMP();  // producer: slot work done
         __syncthreads();
@@ -670,7 +795,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     for (int i = 0; i < RPW; ++i) {
       const int row = row0 + w_e * RPW + i;
       xr[i] = zero_row<G::kQ>();
-      if (row < M) xr[i] = load_row<D>(x + (size_t)row * D, lane_e);
+      if (TR != 2 && row < M) xr[i] = load_row<D>(x + (size_t)row * D, lane_e);
     }
     __builtin_amdgcn_sched_barrier(0);
     constexpr bool more = si + 1 < NS;
@@ -700,7 +825,16 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     const float res_scale = EEC_STAGE_FIELD(si, res_scale);
     const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
     float* tap = EEC_STAGE_FIELD(si, tap);
-    if constexpr (TR) {
+    if constexpr (TR == 2) {  // d(LN(x)) rows, as they are
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w_e * RPW + i;
+        RowV<G::kQ> v;
+#pragma unroll
+        for (int q = 0; q < G::kQ; ++q) v.p[q] = *(const float4*)(lds_e + (w_e * RPW + i) * G::kELd + (q * 256 + lane_e * 4) * 4);
+        if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v, lane_e);
+      }
+    } else if constexpr (TR == 1) {
       // y = x + res_scale * drop(W2 . h + b2): the row pass with the output dropout of the module, rows to a.tr.y
       const eect::DropState ds_res(eect::Drop{a.tr.p, a.tr.seed, a.tr.site_res});
 #pragma unroll
@@ -759,7 +893,7 @@ extern "C" int eec_debug_timeline(unsigned long long* host_out, int n) {
 }
 #endif
 
-template <int D, int NP, int ACT, int FNP, int QNP, int NS, bool TR = false>
+template <int D, int NP, int ACT, int FNP, int QNP, int NS, int TR = 0>
 static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
   auto k = ffn_chain_kernel<D, NP, ACT, FNP, QNP, NS, TR>;
   constexpr int lds = FNP != 0 ? (DwGeo<D>::kLds > FfnGeo<D>::kLds ? DwGeo<D>::kLds : FfnGeo<D>::kLds) : FfnGeo<D>::kLds;
@@ -769,13 +903,23 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
   return hipGetLastError();
 }
 
-#ifdef EEC_FFN_TRAIN
-// Third object of this source (build/ffn_train.o): only the training variants.
+#if defined(EEC_FFN_TRAIN_BWD)
+// Fourth object of this source (build/ffn_train_bwd.o, bf16 operands): the training step's backward variants.
+hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st) {
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
+  if (!a.tr.y || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
+  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 2>(a, st);
+  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 2>(a, st);
+  return hipErrorInvalidValue;
+}
+}  // namespace eec
+#elif defined(EEC_FFN_TRAIN)
+// Third object of this source (build/ffn_train.o): only the training step's forward variants.
 hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st) {
   if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
   if (!a.tr.y || !a.tr.ln || !a.tr.mean || !a.tr.rstd || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
-  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, true>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, true>(a, st);
-  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, true>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, true>(a, st);
+  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 1>(a, st);
+  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 1>(a, st);
   return hipErrorInvalidValue;
 }
 }  // namespace eec

@@ -41,6 +41,33 @@ __global__ void pack_frags_kernel(const float* __restrict__ w, int N, int K, uin
   out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
 }
 
+// The same fragment layout from a strided source, element (n, k) = w[n * ldn + k * ldk], as bf16 hi / lo planes (hi = RNE(x),
+// lo = RNE(x - hi)): the operands of the training step's fused feed-forward backward, which multiplies by W2^T and W1^T.
+__global__ void pack_frags_bf16_kernel(const float* __restrict__ w, int N, int K, long ldn, long ldk, uint4* __restrict__ out, int total) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = idx & 63, frag = idx >> 6;
+  const int KS = K / 16;
+  const int nt = frag / KS, s = frag - nt * KS;
+  const int n = nt * 32 + (lane & 31), k0 = s * 16 + 8 * (lane >> 5);
+  bf8_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float v = (n < N) ? w[(size_t)n * ldn + (size_t)(k0 + j) * ldk] : 0.f;
+    const __bf16 h = (__bf16)v;
+    hi[j] = h;
+    lo[j] = (__bf16)(v - (float)h);
+  }
+  out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
+  out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
+}
+hipError_t launch_pack_frags_bf16(const float* w, int N, int K, long ldn, long ldk, uint4* out, hipStream_t st) {
+  if (K % 16) return hipErrorInvalidValue;
+  const int total = ((N + 31) / 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(pack_frags_bf16_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, N, K, ldn, ldk, out, total);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st) {
   if (K % 16) return hipErrorInvalidValue;
   const int total = ((N + 31) / 32) * (K / 16) * 64;

@@ -198,6 +198,11 @@ bool ffn_fused_fwd_supported(const eec_trainer* tr) {
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
   return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
 }
+bool ffn_fused_bwd_supported(const eec_trainer* tr) {
+  static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED_BWD"); return e && atoi(e) == 0; }();
+  const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
+}
 float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.pre = r.tape.f((size_t)M * F);
@@ -358,6 +363,22 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
   float* dln = r.scr.f((size_t)M * D);  // its own buffer: dh is still being read by the dW2 job
   RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
   linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
+  if (ffn_fused_bwd_supported(r.tr)) {
+    // the data path as ONE launch (ffn.hip, TR = 2): dpre = (dh . W2) * dropmask * silu'(pre) chunk by chunk -- stored once, for the
+    // W1 / b1 gradient -- and dln = dpre . W1 accumulated on chip; W2^T and W1^T as bf16 fragments of this step's parameters
+    float* w1p = r.scr.f((size_t)F * D);
+    float* w2p = r.scr.f((size_t)D * F);
+    RUN(eec::launch_pack_frags_bf16(w2, F, D, 1, F, (uint4*)w1p, r.st));  // (f, d) = W2[d][f]
+    RUN(eec::launch_pack_frags_bf16(w1, D, F, 1, D, (uint4*)w2p, r.st));  // (d, f) = W1[f][d]
+    eec::ChainArgs a{};
+    a.x = dh, a.M = M, a.F = F, a.nstage = 1, a.D = D;
+    a.st[0] = eec::FfnStage{nullptr, nullptr, (const uint4*)w1p, nullptr, (const uint4*)w2p, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, nullptr};
+    a.tr = eec::ChainTrain{dln, nullptr, nullptr, nullptr, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    RUN(eec::launch_ffn_train_bwd(a, r.tr->np, r.st));
+    linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
+    ln_bwd(r, dln, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
+    return;
+  }
   {  // dpre = (dh . W2) * dropmask * silu'(pre), the activation's backward in the GEMM epilogue
     GemmArgs g = gemm_args(dh, D, 1, w2, 1, F, dpre, F, M, F, D);
     g.epi = 2, g.aux = t.pre, g.drop = drop_of(r, t.site_act);

@@ -549,6 +549,14 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   const float* __restrict__ aux = g.aux;
   float* __restrict__ C2 = g.C2;
   const bool cvec = ((((uintptr_t)C) | ((uintptr_t)C2) | ((uintptr_t)aux)) & 15) == 0 && (g.c_m & 3) == 0 && (g.N & 3) == 0;
+  const bool nt = g.stream_out != 0;  // uniform
+  auto store4 = [&](float* p, f32x4 v) __attribute__((always_inline)) {
+    if (nt) __builtin_nontemporal_store(v, (f32x4*)p);
+    else *(f32x4*)p = v;
+  };
+  auto load4 = [&](const float* p) __attribute__((always_inline)) {
+    return nt ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
+  };
   // one group of four consecutive columns of row m: v = alpha * acc + bias, the epilogue arithmetic, 16-byte stores
   auto finish4 = [&](int m, int n, f32x4 a4, f32x4 pre4) __attribute__((always_inline)) {
     const long ci = (long)m * g.c_m + n;
@@ -580,16 +588,16 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = pre4[j] + g.res_scale * v[j] * dm[j];
       }
-      *(f32x4*)(C + ci) = (f32x4){v[0], v[1], v[2], v[3]};
+      store4(C + ci, (f32x4){v[0], v[1], v[2], v[3]});
       if (epi == EPI_SILU) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v2[j] = v[j] * sigmoidf_(v[j]) * dm[j];
-        *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+        store4(C2 + ci, (f32x4){v2[0], v2[1], v2[2], v2[3]});
       }
       if (epi == EPI_RELU_DROP) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) v2[j] = fmaxf(v[j], 0.0f) * dm[j];
-        *(f32x4*)(C2 + ci) = (f32x4){v2[0], v2[1], v2[2], v2[3]};
+        store4(C2 + ci, (f32x4){v2[0], v2[1], v2[2], v2[3]});
       }
     } else {
 #pragma unroll
@@ -689,7 +697,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
     for (int ps = 0; ps < NPS; ++ps) {
       const int idx = ps * 256 + tid, row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
       const int m = m0 + sl * 32 + row, n = n0 + c4;
-      pre[sl][ps] = (want_pre && m < g.M && n < g.N) ? *(const f32x4*)(pre_src + (long)m * g.c_m + n) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+      pre[sl][ps] = (want_pre && m < g.M && n < g.N) ? load4(pre_src + (long)m * g.c_m + n) : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
   };
   request(IntTag<0>{});
@@ -799,8 +807,11 @@ static hipError_t launch_gemm_t(const GemmArgs& g, int np, hipStream_t st) {
 #undef EECT_GEMM_S
   return hipGetLastError();
 }
-hipError_t launch_gemm(const GemmArgs& g, int np, hipStream_t st) {
+hipError_t launch_gemm(const GemmArgs& g_in, int np, hipStream_t st) {
+  GemmArgs g = g_in;
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nz <= 0) return hipSuccess;
+  static const long nt_bytes = [] { const char* e = getenv("EEC_TRAIN_NT_MB"); return (e ? atol(e) : 32L) << 20; }();
+  g.stream_out = nt_bytes > 0 && g.nz == 1 && (long)g.M * g.N * 4 >= nt_bytes;
   if ((g.a_m != 1 && g.a_k != 1) || (g.b_n != 1 && g.b_k != 1)) return hipErrorInvalidValue;
   if (g.epi != EPI_NONE && (g.nz != 1 || g.accumulate)) return hipErrorInvalidValue;  // the epilogues index C as one [M][N] matrix
   if (g.rowsum && (g.a_m != 1 || g.zdiv != 1)) return hipErrorInvalidValue;             // row sums: A row-contiguous, batch = splits
