@@ -173,8 +173,8 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
               o[i] = to_half_sat(v);
               ol[i] = (half_t)(v - (float)o[i]);
             }
-            *(h4*)(dst + 8 * g) = o;
-            if (a.q_lo) *(h4*)(a.q_lo + qoff + 8 * g) = ol;
+            store_maybe_nt<EEC_NT_QKV != 0>((h4*)(dst + 8 * g), o);
+            if (a.q_lo) store_maybe_nt<EEC_NT_QKV != 0>((h4*)(a.q_lo + qoff + 8 * g), ol);
           }
         }
       }
@@ -198,8 +198,8 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
             o[i] = to_half_sat(v);
             ol[i] = (half_t)(v - (float)o[i]);
           }
-          *(h4*)(dst + 8 * g) = o;
-          if (a.k_lo) *(h4*)(a.k_lo + koff + 8 * g) = ol;
+          store_maybe_nt<EEC_NT_QKV != 0>((h4*)(dst + 8 * g), o);
+          if (a.k_lo) store_maybe_nt<EEC_NT_QKV != 0>((h4*)(a.k_lo + koff + 8 * g), ol);
         }
       }
     }
@@ -221,8 +221,8 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
           for (int i = 0; i < 4; ++i) {
             const float v = acc[mt][j][4 * g + i];
             const half_t hi = to_half_sat(v);
-            dst[(size_t)(8 * g + i) * a.Tp] = hi;
-            if (a.vt_lo) a.vt_lo[voff + (size_t)(8 * g + i) * a.Tp] = (half_t)(v - (float)hi);
+            store_maybe_nt<EEC_NT_QKV != 0>(dst + (size_t)(8 * g + i) * a.Tp, hi);
+            if (a.vt_lo) store_maybe_nt<EEC_NT_QKV != 0>(a.vt_lo + voff + (size_t)(8 * g + i) * a.Tp, (half_t)(v - (float)hi));
           }
       }
     }

@@ -49,6 +49,23 @@ typedef __bf16 bf8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+// Streaming-store experiments (profiles/r04_ab_nt_stores.txt): which of the large write-once outputs of the inference kernels carry the
+// non-temporal hint, so that they do not push the weight streams out of the L2.  NT = a compile-time flag per site.
+template <bool NT, typename T>
+__device__ __forceinline__ void store_maybe_nt(T* p, T v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+#ifndef EEC_NT_QKV
+#define EEC_NT_QKV 0
+#endif
+#ifndef EEC_NT_HEAD
+#define EEC_NT_HEAD 0
+#endif
+#ifndef EEC_NT_G
+#define EEC_NT_G 0
+#endif
+
 constexpr int kWave = 64;
 constexpr float kLnEps = 1e-5f;
 constexpr float kLog2e = 1.4426950408889634f;

@@ -148,11 +148,12 @@ struct ChainArgs {
   ChainTrain tr;    // TR variants only
 };
 // the feed-forward module of the training step's forward as one launch (plain-domain SiLU, weights packed with scale 1);
-// np 3 or 1; d_model 256 / 512, F % 32 == 0
+// np = 3 (the split format) only; d_model 256 / 512, F % 32 == 0
 hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st);
-// ... and the data path of its backward as one launch: x = dh [M][D] (the module's output gradient after the residual scale and
-// dropout), st[0].w1p = W2^T as [F][D] and st[0].w2p = W1^T as [D][F] (launch_pack_frags_bf16: bf16 operands), tr.pre read,
-// tr.act <- d(pre) (the operand of the W1 / b1 gradient), tr.y <- d(LN(x)) = d(pre) . W1; no LayerNorm, bias, residual or output dropout
+// ... and the data path of its backward as one launch: x = the gradient of the module's output [M][D]; dh = st[0].res_scale *
+// dropmask(site_res) * x is what gets multiplied, and is stored to tr.ln (the operand of the W2 / b2 gradient); st[0].w1p = W2^T as
+// [F][D] and st[0].w2p = W1^T as [D][F] (bf16 fragments: launch_pack_frags_bf16 / launch_pack_ffn_batch), tr.pre read,
+// tr.act <- d(pre) (the operand of the W1 / b1 gradient), tr.y <- d(LN(x)) = d(pre) . W1; no LayerNorm, bias or residual
 hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st);
 hipError_t launch_ffn_chain(const ChainArgs& a, int np, int np_front, int np_tail, bool front, bool tail, bool relu, hipStream_t st);
 
@@ -174,6 +175,14 @@ hipError_t launch_subsample_single(const SubsampleArgs& a, hipStream_t st);  // 
 // weight packing (device -> device)
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // out may point into a larger matrix: n-tile nt0 of [N'][K] starts at out + nt0*(K/16)*128  // scale*W[N][K] -> fragments
 hipError_t launch_pack_frags_bf16(const float* w, int N, int K, long ldn, long ldk, uint4* out, hipStream_t st);  // element (n, k) = w[n*ldn + k*ldk] -> bf16 hi / lo fragments
+constexpr int kFfnPackModules = 12;
+struct FfnPackJobs {  // see pack.hip pack_ffn_batch_kernel
+  const float* w1[kFfnPackModules];   // [F][D]
+  const float* w2[kFfnPackModules];   // [D][F]
+  uint4* out[kFfnPackModules][4];     // F * D * 4 bytes each
+  int n;
+};
+hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, hipStream_t st);
 hipError_t launch_pack_frags_f8(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // NP == 8 stream (K % 64 == 0)
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,

@@ -443,7 +443,31 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
   } else {
     const WPtrs W0 = wptrs(0);
     if constexpr (TR == 2) {
-      rows_f32_to_planes<D, NP, false>(smem, x, row0, M, nullptr, nullptr, [&]() { start_streams(W0); });
+      // x = the gradient of the module's output; dh = res_scale * dropmask_res(x) are the rows this launch multiplies -- and, stored to
+      // a.tr.ln, the operand of the W2 / b2 gradient
+      const eect::DropState ds_res(eect::Drop{a.tr.p, a.tr.seed, a.tr.site_res});
+      const float rsc = a.st[0].res_scale;
+      RowV<G::kQ> v[RPW];
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w * RPW + i;
+        v[i] = zero_row<G::kQ>();
+        if (row < M) v[i] = load_row<D>(x + (size_t)row * D, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      start_streams(W0);
+#pragma unroll
+      for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + w * RPW + i;
+#pragma unroll
+        for (int q = 0; q < G::kQ; ++q) {
+          float m[4];
+          ds_res.mul4((size_t)row * D + q * 256 + lane * 4, m);
+          v[i].p[q].x *= rsc * m[0], v[i].p[q].y *= rsc * m[1], v[i].p[q].z *= rsc * m[2], v[i].p[q].w *= rsc * m[3];
+        }
+        if (row < M) store_row<D>(a.tr.ln + (size_t)row * D, v[i], lane);
+      }
+      rows_to_planes<D, NP, RPW>(smem, v, w * RPW, row0, M, false);
     } else if constexpr (TR == 1) {  // as rows_f32_to_planes, and the LayerNormed rows and their statistics go to the tape
       const RowV<G::kQ> lg = load_row<D>(a.st[0].ln_g, lane), lb = load_row<D>(a.st[0].ln_b, lane);
       RowV<G::kQ> v[RPW];
@@ -906,20 +930,20 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
 #if defined(EEC_FFN_TRAIN_BWD)
 // Fourth object of this source (build/ffn_train_bwd.o, bf16 operands): the training step's backward variants.
 hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st) {
-  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
-  if (!a.tr.y || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
-  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 2>(a, st);
-  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 2>(a, st);
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || np != 3) return hipErrorInvalidValue;
+  if (!a.tr.y || !a.tr.pre || !a.tr.act || !a.tr.ln) return hipErrorInvalidValue;
+  if (a.D == 256) return launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st);
+  if (a.D == 512) return launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st);
   return hipErrorInvalidValue;
 }
 }  // namespace eec
 #elif defined(EEC_FFN_TRAIN)
 // Third object of this source (build/ffn_train.o): only the training step's forward variants.
 hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st) {
-  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || np != 3) return hipErrorInvalidValue;
   if (!a.tr.y || !a.tr.ln || !a.tr.mean || !a.tr.rstd || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
-  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 1>(a, st);
-  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 1>(a, st);
+  if (a.D == 256) return launch_chain_t<256, 3, 2, 0, 0, 1, 1>(a, st);
+  if (a.D == 512) return launch_chain_t<512, 3, 2, 0, 0, 1, 1>(a, st);
   return hipErrorInvalidValue;
 }
 }  // namespace eec

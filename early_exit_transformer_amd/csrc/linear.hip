@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
             const float gate = ag[mt][j][4 * g + i];
             o[i] = to_half_sat(av[mt][j][4 * g + i] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * gate)));
           }
-          *(h4*)(dst + 8 * g) = o;
+          store_maybe_nt<EEC_NT_G != 0>((h4*)(dst + 8 * g), o);
         }
       }
     }
@@ -526,7 +526,7 @@ __device__ __forceinline__ void head_body(char* smem, const HeadArgs& a) {
     const float mx = wave_max(fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
     const float sm = wave_sum(has ? __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx) : 0.f);
     const float lse = mx + __logf(sm);
-    if (has && row < a.M) *(float4*)(a.out + (size_t)row * a.V + c0) = make_float4(v.x - lse, v.y - lse, v.z - lse, v.w - lse);
+    if (has && row < a.M) store_maybe_nt<EEC_NT_HEAD != 0>((f32x4*)(a.out + (size_t)row * a.V + c0), (f32x4){v.x - lse, v.y - lse, v.z - lse, v.w - lse});
   }
 }
 

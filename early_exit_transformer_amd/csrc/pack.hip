@@ -68,6 +68,47 @@ hipError_t launch_pack_frags_bf16(const float* w, int N, int K, long ldn, long l
   return hipGetLastError();
 }
 
+// All four fragment images of up to kFfnPackModules feed-forward modules in ONE launch (the training step packs this step's W1 / W2
+// of every module at the start of its forward: 96 launches of 5 us otherwise).  Per module: out[0] = W1 as [F][D] and out[1] = W2 as
+// [D][F], fp16 hi / lo (the forward's operands); out[2] = W2^T as [F][D] and out[3] = W1^T as [D][F], bf16 hi / lo (the backward's).
+__global__ void pack_ffn_batch_kernel(FfnPackJobs jb, int F, int D) {
+  const int bpj = F * D / 8 / 256;  // blocks per image (every image has F * D / 8 threads)
+  const int job = blockIdx.x / bpj, mod = job >> 2, kind = job & 3;
+  const int idx = (blockIdx.x - job * bpj) * 256 + threadIdx.x;
+  const int N = (kind & 1) ? D : F, K = (kind & 1) ? F : D;
+  const float* __restrict__ w = (kind == 0 || kind == 3) ? jb.w1[mod] : jb.w2[mod];
+  uint4* __restrict__ out = jb.out[mod][kind];
+  const long ldn = kind < 2 ? K : 1, ldk = kind < 2 ? 1 : N;
+  const int lane = idx & 63, frag = idx >> 6, KS = K / 16;
+  const int nt = frag / KS, s = frag - nt * KS;
+  const int n = nt * 32 + (lane & 31), k0 = s * 16 + 8 * (lane >> 5);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = w[(size_t)n * ldn + (size_t)(k0 + j) * ldk];
+  if (kind < 2) {
+    h8 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) EEC_SPLIT(v[j], hi, lo, j);
+    out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
+    out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
+  } else {
+    bf8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      hi[j] = h;
+      lo[j] = (__bf16)(v[j] - (float)h);
+    }
+    out[(size_t)frag * 128 + lane] = __builtin_bit_cast(uint4, hi);
+    out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
+  }
+}
+hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, hipStream_t st) {
+  if (jb.n < 1 || jb.n > kFfnPackModules || F % 32 || D % 32 || (F * D / 8) % 256) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_ffn_batch_kernel, dim3((unsigned)(jb.n * 4 * (F * D / 8 / 256))), dim3(256), 0, st, jb, F, D);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack_frags(const float* w, int N, int K, uint4* out, float scale, hipStream_t st) {
   if (K % 16) return hipErrorInvalidValue;
   const int total = ((N + 31) / 32) * (K / 16) * 64;

@@ -45,6 +45,9 @@ struct Bump {  // bump allocator; base == nullptr: sizes only
 struct FfnTape {
   float *x, *ln, *mean, *rstd, *pre, *act;
   uint32_t site_act, site_res;
+  // fused path: this step's W1 / W2 as MFMA fragments (pack_ffn_weights): [0], [1] the forward's (fp16 pairs), [2], [3] the backward's
+  // transposes (bf16 pairs)
+  uint4* wp[4];
 };
 struct AttnTape {
   float *x, *ln, *mean, *rstd, *qkv, *P, *Pd, *ctx;  // Pd: drop(P), kept for the backward (== P when drop_prob is 0)
@@ -196,12 +199,37 @@ void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const floa
 bool ffn_fused_fwd_supported(const eec_trainer* tr) {
   static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED"); return e && atoi(e) == 0; }();
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
-  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
 }
 bool ffn_fused_bwd_supported(const eec_trainer* tr) {
   static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED_BWD"); return e && atoi(e) == 0; }();
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
-  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
+}
+// Fragment images of every feed-forward module's W1 / W2, for both directions of the step, carved from the tape and made by one
+// launch per 12 modules.  Called at the start of a forward, before the layers (the sizing passes carve the same way).
+void pack_ffn_weights(Run& r, const eec_layer_params* layers, int n_layers) {
+  eec_trainer* tr = r.tr;
+  const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
+  // carved by geometry alone (the tape layout must not depend on the operand mode of a particular step); filled when a fused path runs
+  if (!((D == 256 || D == 512) && F >= 32 && F % 32 == 0)) return;
+  const bool fill = ffn_fused_fwd_supported(tr) || ffn_fused_bwd_supported(tr);
+  eec::FfnPackJobs jb{};
+  auto flush = [&]() {
+    if (jb.n > 0) RUN(eec::launch_pack_ffn_batch(jb, F, D, r.st));
+    jb.n = 0;
+  };
+  for (int l = 0; l < n_layers; ++l)
+    for (int m = 0; m < 2; ++m) {
+      FfnTape& t = m == 0 ? tr->lt[l].f1 : tr->lt[l].f2;
+      for (int k = 0; k < 4; ++k) t.wp[k] = (uint4*)r.tape.f((size_t)F * D);
+      if (r.dry || !layers || !fill) continue;
+      const eec_layer_params& L = layers[l];
+      jb.w1[jb.n] = m == 0 ? L.ffn1_w1 : L.ffn2_w1, jb.w2[jb.n] = m == 0 ? L.ffn1_w2 : L.ffn2_w2;
+      for (int k = 0; k < 4; ++k) jb.out[jb.n][k] = t.wp[k];
+      if (++jb.n == eec::kFfnPackModules) flush();
+    }
+  flush();
 }
 float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
@@ -211,16 +239,11 @@ float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_
   if (ffn_fused_fwd_supported(r.tr)) {
     // ONE launch (ffn.hip, TR variants of the chain kernel): LayerNorm, both GEMMs, SiLU, both dropout sites and the residual; the
     // [M, F] tensors are written to the tape from the accumulators and never read back by the forward.  Its GEMMs run on split
-    // fp16 fragments of THIS step's parameters: packed here, 2 x 2 MB per module.
-    r.scr.reset();
-    float* w1p = r.scr.f((size_t)F * D);
-    float* w2p = r.scr.f((size_t)D * F);
+    // fp16 fragments of THIS step's parameters (pack_ffn_weights, at the start of the forward).
     float* y = r.tape.f((size_t)M * D);
-    RUN(eec::launch_pack_frags(w1, F, D, (uint4*)w1p, 1.0f, r.st));
-    RUN(eec::launch_pack_frags(w2, D, F, (uint4*)w2p, 1.0f, r.st));
     eec::ChainArgs a{};
     a.x = x, a.M = M, a.F = F, a.nstage = 1, a.D = D;
-    a.st[0] = eec::FfnStage{ln_w, ln_b, (const uint4*)w1p, b1, (const uint4*)w2p, b2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
+    a.st[0] = eec::FfnStage{ln_w, ln_b, t.wp[0], b1, t.wp[1], b2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
     a.tr = eec::ChainTrain{y, t.ln, t.mean, t.rstd, t.pre, t.act, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
     RUN(eec::launch_ffn_train_fwd(a, r.tr->np, r.st));
     return y;
@@ -332,6 +355,7 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
     RUN(launch_gemm(g, tr->np, r.st));
   }
   RUN(launch_add_pe_drop(x, P->pe, B, Tq, D, drop_of(r, tr->site_pe), r.st));
+  pack_ffn_weights(r, P->layers, nl);
   for (int e = 0; e < c.n_exits; ++e) {
     for (int l = 0; l < c.layers_per_exit; ++l) {
       const int li = e * c.layers_per_exit + l;
@@ -361,24 +385,21 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
   float* dh = r.scr.f((size_t)M * D);
   float* dpre = r.scr.f((size_t)M * F);
   float* dln = r.scr.f((size_t)M * D);  // its own buffer: dh is still being read by the dW2 job
-  RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
-  linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
   if (ffn_fused_bwd_supported(r.tr)) {
     // the data path as ONE launch (ffn.hip, TR = 2): dpre = (dh . W2) * dropmask * silu'(pre) chunk by chunk -- stored once, for the
     // W1 / b1 gradient -- and dln = dpre . W1 accumulated on chip; W2^T and W1^T as bf16 fragments of this step's parameters
-    float* w1p = r.scr.f((size_t)F * D);
-    float* w2p = r.scr.f((size_t)D * F);
-    RUN(eec::launch_pack_frags_bf16(w2, F, D, 1, F, (uint4*)w1p, r.st));  // (f, d) = W2[d][f]
-    RUN(eec::launch_pack_frags_bf16(w1, D, F, 1, D, (uint4*)w2p, r.st));  // (d, f) = W1[f][d]
     eec::ChainArgs a{};
-    a.x = dh, a.M = M, a.F = F, a.nstage = 1, a.D = D;
-    a.st[0] = eec::FfnStage{nullptr, nullptr, (const uint4*)w1p, nullptr, (const uint4*)w2p, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, nullptr};
-    a.tr = eec::ChainTrain{dln, nullptr, nullptr, nullptr, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    a.x = dx, a.M = M, a.F = F, a.nstage = 1, a.D = D;
+    a.st[0] = eec::FfnStage{nullptr, nullptr, t.wp[2], nullptr, t.wp[3], nullptr, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
+    a.tr = eec::ChainTrain{dln, dh, nullptr, nullptr, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
     RUN(eec::launch_ffn_train_bwd(a, r.tr->np, r.st));
+    linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
     linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
     ln_bwd(r, dln, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
     return;
   }
+  RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
+  linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
   {  // dpre = (dh . W2) * dropmask * silu'(pre), the activation's backward in the GEMM epilogue
     GemmArgs g = gemm_args(dh, D, 1, w2, 1, F, dpre, F, M, F, D);
     g.epi = 2, g.aux = t.pre, g.drop = drop_of(r, t.site_act);
@@ -705,6 +726,7 @@ void group_forward(Run& r, const eec_layer_params* layers, int n_layers, const f
   tr->lt.assign(n_layers, LayerTape{});
   float* x = (float*)x_in;
   static const eec_layer_params kNone{};
+  pack_ffn_weights(r, layers, n_layers);
   for (int l = 0; l < n_layers; ++l) {
     const eec_layer_params& L = layers ? layers[l] : kNone;
     LayerTape& t = tr->lt[l];

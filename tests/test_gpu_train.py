@@ -345,12 +345,15 @@ def test_single_rank_rccl_runs_every_collective_of_the_training_step():
     assert backend == "nccl" and n_coll == 3 and same and loss_ok
 
 
-@pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2)], ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention"])
+@pytest.mark.parametrize("cfg", [SMALL, dict(SMALL, n_head=2), dict(SMALL, d_model=256, n_head=8)],
+                         ids=["head_dim_16_unfused_attention", "head_dim_32_fused_attention", "d_model_256_fused_feed_forward"])
 def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     """drop_prob > 0: streams cannot match torch's, so the check is internal -- the same seed reproduces the step, another
     seed changes it, and the analytic gradient matches a central finite difference of the SAME masked network along a
     random direction in parameter space.  Both attention paths: batched GEMMs + softmax kernels (head dim 16) and the fused
-    kernels that regenerate the attention-probability mask in three places (head dim 32)."""
+    kernels that regenerate the attention-probability mask in three places (head dim 32).  d_model 256: the feed-forward modules
+    run as one launch per direction (csrc/ffn.hip TR variants; d_ff 160 = one full chunk of 128 hidden units and a 32-wide rest) --
+    the forward applies both of the module's masks, the backward regenerates the activation's."""
     kw = base_kwargs(**cfg)
     _, gpu = make_train_pair(kw, seed=5, drop=0.1)
     mel, lens = synth.synth_mel(2, 80, 99, seed=5).cuda(), torch.tensor([99, 70])
@@ -375,7 +378,9 @@ def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
     assert torch.isfinite(o1).all() and (o1 - o0).abs().max().item() > 1e-3  # dropout is active
 
     gen = torch.Generator().manual_seed(0)
-    names = ["conformer.0.conformer_layers.0.ffn1.sequential.1.weight", "conformer.1.conformer_layers.1.self_attn.in_proj_weight",
+    names = ["conformer.0.conformer_layers.0.ffn1.sequential.1.weight", "conformer.1.conformer_layers.0.ffn2.sequential.4.weight",
+             "conformer.1.conformer_layers.1.ffn1.sequential.0.weight",  # W1 and W2 of feed-forward modules, and a module's LayerNorm
+             "conformer.1.conformer_layers.1.self_attn.in_proj_weight",
              "conformer.0.conformer_layers.1.conv_module.sequential.2.weight", "conv_subsample.sequential.1.weight", "linears.1.bias"]
     params = dict(gpu.named_parameters())
     for n in names:

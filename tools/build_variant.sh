@@ -18,5 +18,5 @@ for s in capi ffn linear attention conv stem ctc pack frontend ctc_beam train_ke
     objs="$objs build/$s.o"
   fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs build/ffn512.o -o libeec_$name.so
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $objs build/ffn512.o build/ffn_train.o build/ffn_train_bwd.o -o libeec_$name.so
 echo built libeec_$name.so

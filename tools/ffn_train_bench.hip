@@ -1,6 +1,7 @@
 // Stand-alone timing of the training step's fused feed-forward forward (csrc/ffn.hip, TR variants) with its ablation builds:
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I early_exit_transformer_amd/csrc -DEEC_FFN_TRAIN [-DEEC_TR_ABLATE=n] [-DEEC_SIDE_VALU_NP3=n]
-//         tools/ffn_train_bench.hip early_exit_transformer_amd/csrc/build/pack.o -o tools/ffn_train_bench
+//         tools/ffn_train_bench.hip early_exit_transformer_amd/csrc/pack.hip -o tools/ffn_train_bench
+// (-DEEC_FFN_TRAIN_BWD instead of -DEEC_FFN_TRAIN: the backward variant)
 // M = 16384 rows, d_model 256, F = 2048, p = 0.1 and p = 0; six weight sets in rotation (as consecutive modules do), HIP events.
 // Numerics are the training tests' business (tests/test_gpu_train.py); this prints one checksum so that ablations are visibly different.
 #include <math.h>
@@ -27,7 +28,7 @@ static T* dev(const std::vector<T>& h) {
 }
 
 int main(int argc, char** argv) {
-  const int D = 256, F = 2048, M = argc > 1 ? atoi(argv[1]) : 16384, NSET = 6;
+  const int D = 256, F = 2048, M = argc > 1 ? atoi(argv[1]) : 16384, NSET = 6, np = argc > 2 ? atoi(argv[2]) : 3;
   std::vector<float> w1((size_t)F * D), w2((size_t)D * F), b1(F), b2(D), g(D), b(D), x((size_t)M * D);
   const float a1 = sqrtf(6.0f / (F + D));
   for (auto& v : w1) v = urand() * a1;
@@ -41,8 +42,13 @@ int main(int argc, char** argv) {
   for (int i = 0; i < NSET; ++i) {
     CK(hipMalloc(&w1p[i], (size_t)F * D * 4));
     CK(hipMalloc(&w2p[i], (size_t)F * D * 4));
+#ifdef EEC_FFN_TRAIN_BWD  // backward: W2^T as [F][D], W1^T as [D][F], bf16 fragments
+    CK(eec::launch_pack_frags_bf16(dw2, F, D, 1, F, w1p[i], 0));
+    CK(eec::launch_pack_frags_bf16(dw1, D, F, 1, D, w2p[i], 0));
+#else
     CK(eec::launch_pack_frags(dw1, F, D, w1p[i], 1.0f, 0));
     CK(eec::launch_pack_frags(dw2, D, F, w2p[i], 1.0f, 0));
+#endif
   }
   float *y, *ln, *mean, *rstd, *pre[2], *act[2];
   CK(hipMalloc(&y, (size_t)M * D * 4));
@@ -52,6 +58,7 @@ int main(int argc, char** argv) {
   for (int i = 0; i < 2; ++i) {
     CK(hipMalloc(&pre[i], (size_t)M * F * 4));
     CK(hipMalloc(&act[i], (size_t)M * F * 4));
+    CK(hipMemset(pre[i], 0, (size_t)M * F * 4));
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
@@ -63,7 +70,12 @@ int main(int argc, char** argv) {
       a.x = dx, a.M = M, a.F = F, a.nstage = 1, a.D = D;
       a.st[0] = eec::FfnStage{dg, dbt, w1p[i % NSET], db1, w2p[i % NSET], db2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
       a.tr = eec::ChainTrain{y, ln, mean, rstd, pre[i & 1], act[i & 1], p, 1234ull, (unsigned)(2 * i + 1), (unsigned)(2 * i + 2)};
-      CK(eec::launch_ffn_train_fwd(a, 3, 0));
+#ifdef EEC_FFN_TRAIN_BWD  // x = dh; pre[] read (whatever the forward mode left there: any finite values do for timing), act[] <- d(pre)
+      a.st[0].ln_g = a.st[0].ln_b = a.st[0].b1 = a.st[0].b2 = nullptr, a.st[0].res_scale = 1.0f;
+      CK(eec::launch_ffn_train_bwd(a, np, 0));
+#else
+      CK(eec::launch_ffn_train_fwd(a, np, 0));
+#endif
     };
     for (int i = 0; i < 6; ++i) run(i);
     CK(hipDeviceSynchronize());
@@ -83,7 +95,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(yo.data(), y + (size_t)(M / 2) * D, 4096, hipMemcpyDeviceToHost));
     double cs = 0;
     for (float v : yo) cs += v;
-    printf("M=%d p=%.1f ablate=%d side_valu=%d: %.2f us per launch (best of 4 x %d; mean %.2f)  checksum %.6f\n", M, p, EEC_TR_ABLATE, EEC_SIDE_VALU_NP3,
+    printf("M=%d np=%d p=%.1f ablate=%d side_valu=%d: %.2f us per launch (best of 4 x %d; mean %.2f)  checksum %.6f\n", M, np, p, EEC_TR_ABLATE, EEC_SIDE_VALU_NP3,
            best * 1e3, N, total / 4 * 1e3, cs);
   }
   return 0;
