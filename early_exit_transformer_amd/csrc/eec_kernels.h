@@ -182,7 +182,7 @@ struct FfnPackJobs {  // see pack.hip pack_ffn_batch_kernel
   uint4* out[kFfnPackModules][4];     // F * D * 4 bytes each
   int n;
 };
-hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, hipStream_t st);
+hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, int kind0, int nk, hipStream_t st);  // images kind0 .. kind0 + nk - 1
 hipError_t launch_pack_frags_f8(const float* w, int N, int K, uint4* out, float scale, hipStream_t st);  // NP == 8 stream (K % 64 == 0)
 hipError_t launch_scale_copy(const float* src, float* dst, int n, float scale, hipStream_t st);
 hipError_t launch_fold_dw(const float* dw_w, const float* dw_b, const float* bn_w, const float* bn_b,

@@ -68,12 +68,13 @@ hipError_t launch_pack_frags_bf16(const float* w, int N, int K, long ldn, long l
   return hipGetLastError();
 }
 
-// All four fragment images of up to kFfnPackModules feed-forward modules in ONE launch (the training step packs this step's W1 / W2
-// of every module at the start of its forward: 96 launches of 5 us otherwise).  Per module: out[0] = W1 as [F][D] and out[1] = W2 as
+// Fragment images of up to kFfnPackModules feed-forward modules in ONE launch.  (The training step packs a module's two images for a
+// direction right before that direction's fused launch: packed for the whole model at the start of the forward, 192 MB, they have left
+// the Infinity Cache by the time they are streamed -- the forward's fused launch then takes 192 instead of 136 us.)  Per module: out[0] = W1 as [F][D] and out[1] = W2 as
 // [D][F], fp16 hi / lo (the forward's operands); out[2] = W2^T as [F][D] and out[3] = W1^T as [D][F], bf16 hi / lo (the backward's).
-__global__ void pack_ffn_batch_kernel(FfnPackJobs jb, int F, int D) {
+__global__ void pack_ffn_batch_kernel(FfnPackJobs jb, int F, int D, int kind0, int nk) {  // images kind0 .. kind0 + nk - 1 of every module
   const int bpj = F * D / 8 / 256;  // blocks per image (every image has F * D / 8 threads)
-  const int job = blockIdx.x / bpj, mod = job >> 2, kind = job & 3;
+  const int job = blockIdx.x / bpj, mod = job / nk, kind = kind0 + job - mod * nk;
   const int idx = (blockIdx.x - job * bpj) * 256 + threadIdx.x;
   const int N = (kind & 1) ? D : F, K = (kind & 1) ? F : D;
   const float* __restrict__ w = (kind == 0 || kind == 3) ? jb.w1[mod] : jb.w2[mod];
@@ -103,9 +104,9 @@ __global__ void pack_ffn_batch_kernel(FfnPackJobs jb, int F, int D) {
     out[(size_t)frag * 128 + 64 + lane] = __builtin_bit_cast(uint4, lo);
   }
 }
-hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, hipStream_t st) {
-  if (jb.n < 1 || jb.n > kFfnPackModules || F % 32 || D % 32 || (F * D / 8) % 256) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pack_ffn_batch_kernel, dim3((unsigned)(jb.n * 4 * (F * D / 8 / 256))), dim3(256), 0, st, jb, F, D);
+hipError_t launch_pack_ffn_batch(const FfnPackJobs& jb, int F, int D, int kind0, int nk, hipStream_t st) {
+  if (jb.n < 1 || jb.n > kFfnPackModules || F % 32 || D % 32 || (F * D / 8) % 256 || kind0 < 0 || nk < 1 || kind0 + nk > 4) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pack_ffn_batch_kernel, dim3((unsigned)(jb.n * nk * (F * D / 8 / 256))), dim3(256), 0, st, jb, F, D, kind0, nk);
   return hipGetLastError();
 }
 

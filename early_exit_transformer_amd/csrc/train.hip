@@ -206,30 +206,24 @@ bool ffn_fused_bwd_supported(const eec_trainer* tr) {
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
   return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
 }
-// Fragment images of every feed-forward module's W1 / W2, for both directions of the step, carved from the tape and made by one
-// launch per 12 modules.  Called at the start of a forward, before the layers (the sizing passes carve the same way).
-void pack_ffn_weights(Run& r, const eec_layer_params* layers, int n_layers) {
+// Room for the fragment images of every feed-forward module's W1 / W2 (4 x F x D x 4 bytes per module), carved from the tape at the
+// start of a forward by geometry alone (the tape layout must not depend on the operand mode of a particular step); a module's images
+// for a direction are made right before that direction's fused launch (pack_ffn_module).
+void carve_ffn_weights(Run& r, int n_layers) {
   eec_trainer* tr = r.tr;
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
-  // carved by geometry alone (the tape layout must not depend on the operand mode of a particular step); filled when a fused path runs
   if (!((D == 256 || D == 512) && F >= 32 && F % 32 == 0)) return;
-  const bool fill = ffn_fused_fwd_supported(tr) || ffn_fused_bwd_supported(tr);
-  eec::FfnPackJobs jb{};
-  auto flush = [&]() {
-    if (jb.n > 0) RUN(eec::launch_pack_ffn_batch(jb, F, D, r.st));
-    jb.n = 0;
-  };
   for (int l = 0; l < n_layers; ++l)
     for (int m = 0; m < 2; ++m) {
       FfnTape& t = m == 0 ? tr->lt[l].f1 : tr->lt[l].f2;
       for (int k = 0; k < 4; ++k) t.wp[k] = (uint4*)r.tape.f((size_t)F * D);
-      if (r.dry || !layers || !fill) continue;
-      const eec_layer_params& L = layers[l];
-      jb.w1[jb.n] = m == 0 ? L.ffn1_w1 : L.ffn2_w1, jb.w2[jb.n] = m == 0 ? L.ffn1_w2 : L.ffn2_w2;
-      for (int k = 0; k < 4; ++k) jb.out[jb.n][k] = t.wp[k];
-      if (++jb.n == eec::kFfnPackModules) flush();
     }
-  flush();
+}
+void pack_ffn_module(Run& r, const FfnTape& t, const float* w1, const float* w2, int kind0) {  // kind0 0: forward images, 2: backward
+  eec::FfnPackJobs jb{};
+  jb.w1[0] = w1, jb.w2[0] = w2, jb.n = 1;
+  for (int k = 0; k < 4; ++k) jb.out[0][k] = t.wp[k];
+  RUN(eec::launch_pack_ffn_batch(jb, r.tr->cfg.d_ff, r.tr->cfg.d_model, kind0, 2, r.st));
 }
 float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
@@ -239,8 +233,9 @@ float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_
   if (ffn_fused_fwd_supported(r.tr)) {
     // ONE launch (ffn.hip, TR variants of the chain kernel): LayerNorm, both GEMMs, SiLU, both dropout sites and the residual; the
     // [M, F] tensors are written to the tape from the accumulators and never read back by the forward.  Its GEMMs run on split
-    // fp16 fragments of THIS step's parameters (pack_ffn_weights, at the start of the forward).
+    // fp16 fragments of THIS step's parameters, made right before it.
     float* y = r.tape.f((size_t)M * D);
+    pack_ffn_module(r, t, w1, w2, 0);
     eec::ChainArgs a{};
     a.x = x, a.M = M, a.F = F, a.nstage = 1, a.D = D;
     a.st[0] = eec::FfnStage{ln_w, ln_b, t.wp[0], b1, t.wp[1], b2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
@@ -355,7 +350,7 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
     RUN(launch_gemm(g, tr->np, r.st));
   }
   RUN(launch_add_pe_drop(x, P->pe, B, Tq, D, drop_of(r, tr->site_pe), r.st));
-  pack_ffn_weights(r, P->layers, nl);
+  carve_ffn_weights(r, nl);
   for (int e = 0; e < c.n_exits; ++e) {
     for (int l = 0; l < c.layers_per_exit; ++l) {
       const int li = e * c.layers_per_exit + l;
@@ -388,6 +383,7 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
   if (ffn_fused_bwd_supported(r.tr)) {
     // the data path as ONE launch (ffn.hip, TR = 2): dpre = (dh . W2) * dropmask * silu'(pre) chunk by chunk -- stored once, for the
     // W1 / b1 gradient -- and dln = dpre . W1 accumulated on chip; W2^T and W1^T as bf16 fragments of this step's parameters
+    pack_ffn_module(r, t, w1, w2, 2);
     eec::ChainArgs a{};
     a.x = dx, a.M = M, a.F = F, a.nstage = 1, a.D = D;
     a.st[0] = eec::FfnStage{nullptr, nullptr, t.wp[2], nullptr, t.wp[3], nullptr, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
@@ -726,7 +722,7 @@ void group_forward(Run& r, const eec_layer_params* layers, int n_layers, const f
   tr->lt.assign(n_layers, LayerTape{});
   float* x = (float*)x_in;
   static const eec_layer_params kNone{};
-  pack_ffn_weights(r, layers, n_layers);
+  carve_ffn_weights(r, n_layers);
   for (int l = 0; l < n_layers; ++l) {
     const eec_layer_params& L = layers ? layers[l] : kNone;
     LayerTape& t = tr->lt[l];

@@ -12,7 +12,9 @@ for r in range(rounds):
         env = dict(os.environ, EEC_LIB_PATH=os.path.abspath(path), **dict(e.split("=", 1) for e in extra))
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_step_time.py")], cwd=ROOT, env=env, capture_output=True, text=True)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        if line: res[n].append(json.loads(line[-1])["train_ms"])
+        if line:
+            rec = json.loads(line[-1]); res[n].append(rec["train_ms"])
+            print(n, " ".join(f"{k}={v:.3f}" for k, v in rec.items()), flush=True)
         else: print(n, "FAILED", out.stderr[-300:])
 for n, v in res.items():
     if v: print(f"{n:12s} train step ms median {statistics.median(v):.3f} min {min(v):.3f}")

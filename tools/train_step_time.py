@@ -25,4 +25,16 @@ for _ in range(3):
     t = time.perf_counter()
     for _ in range(5): step()
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t) / 5 * 1e3)
-print(json.dumps({"train_ms": sorted(ts)[1], "min_ms": min(ts)}))
+# phases by device events (each phase synchronised: the sum is a little above the pipelined step)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+ph = []
+for _ in range(5):
+    opt.zero_grad(set_to_none=True); ev[0].record()
+    out = m(mel, lens); ev[1].record()
+    loss = exit_ctc_losses(out, tgt, tl).sum(); ev[2].record()
+    loss.backward(); ev[3].record()
+    torch.nn.utils.clip_grad_norm_(params, 1.0); opt.step(); ev[4].record()
+    torch.cuda.synchronize()
+    ph.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+ph = [sorted(c)[2] for c in zip(*ph)]
+print(json.dumps({"train_ms": sorted(ts)[1], "min_ms": min(ts), "forward_ms": ph[0], "loss_ms": ph[1], "backward_ms": ph[2], "clip_adamw_ms": ph[3]}))
