@@ -320,6 +320,9 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
 #ifndef EEC_WARM_SLOTS
 #define EEC_WARM_SLOTS 4  // slots before the end of a stage at which the consumers start the L2 warm-up
 #endif
+#ifndef EEC_WARM_PROD
+#define EEC_WARM_PROD 0  // experiment: 1 = the producers issue the warm-up, one touch per slot right before the barrier
+#endif
 #ifndef EEC_FFN_ROT
 #define EEC_FFN_ROT 0
 #endif
@@ -693,6 +696,9 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
       // one slot: GEMM1 of chunk s into `cur` while the SiLU of chunk s-1 (held in `prev`) rides along
       // the SiLU side work of one chunk = 8 MT value pairs, spread over the KS k-steps of the next chunk's GEMM1
       constexpr int kSideEvery = KS / (8 * MT);  // 1 (D = 256) / 4 (D = 512)
+#if EEC_WARM_SLOTS > 0 && EEC_WARM_PROD
+      unsigned warm_p[4] = {0u, 0u, 0u, 0u};
+#endif
       auto slot = [&](int s, f32x16 (&cur)[MT][1], f32x16 (&prev)[MT][1]) {
         const int ft = (s < nchunk ? phys(s) : s) * 4 + wl;  // s >= nchunk: no GEMM1 (ft is out of range)
         const bool do_gemm = s < nchunk && ft < nft;
@@ -730,6 +736,28 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
         if constexpr (TR == 1 && EEC_TR_BURST) {
           if (do_silu) tape_burst(prev, hcol_prev);
         }
+#if EEC_WARM_SLOTS > 0 && EEC_WARM_PROD
+        // L2 warm-up for the stage boundary from the PRODUCERS, right before the barrier they wait at anyway (the consumers are the longer
+        // role of the split format: the touches' cold misses retire in order with their ring loads); one touch per slot
+        if constexpr (!TR) {
+          const int wk = s - (nslots - EEC_WARM_SLOTS);
+          if (wk >= 0 && wk < 4) {
+            const int lane_t = fresh_lane();
+            unsigned t = 0;
+            if constexpr (si + 1 < NS) {
+              const WPtrs Wn = wptrs(si + 1);
+              const size_t wbytes = NP == 8 ? (size_t)(F / 32) * (D / 64) * kF8Rec * 16 : (size_t)F * D * 2 * (NP == 3 ? 2 : 1);
+              const void* base = (wk & 2) ? (NP == 8 ? (const void*)Wn.w2f8 : (const void*)Wn.w2p) : (NP == 8 ? (const void*)Wn.w1f8 : (const void*)Wn.w1p);
+              t = touch_share(base, wbytes, wl_s, wk & 1, lane_t);
+            } else if constexpr (QNP != 0) {
+              if (wk == 0)
+                t = QNP == 8 ? touch_share(a.qkv.wf8, (size_t)(3 * D / 32) * (D / 64) * kF8Rec * 16, wl_s, 0, lane_t)
+                             : touch_share(a.qkv.wp, (size_t)3 * D * D * 2 * (QNP == 3 ? 2 : 1), wl_s, 0, lane_t);
+            }
+            warm_p[wk] = t;
+          }
+        }
+#endif
         TL_STAMP();  // producer: slot work done
         __syncthreads();
         TL_STAMP();  // producer: barrier passed
@@ -739,17 +767,20 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
         slot(s, accA, accB);
         if (s + 1 < nslots) slot(s + 1, accB, accA);
       }
+#if EEC_WARM_SLOTS > 0 && EEC_WARM_PROD
+      sink ^= warm_p[0] ^ warm_p[1] ^ warm_p[2] ^ warm_p[3];
+#endif
     } else {
 #pragma unroll
       for (int h = 0; h < NH; ++h) zero_acc(acc2c[h]);
-#if EEC_WARM_SLOTS > 0
+#if EEC_WARM_SLOTS > 0 && !EEC_WARM_PROD
       unsigned warm[4] = {0u, 0u, 0u, 0u};
 #endif
 #if EEC_ROLL_WARM > 0
       unsigned roll_prev = 0u;
 #endif
       for (int s = 0; s < nslots; ++s) {
-#if EEC_WARM_SLOTS > 0
+#if EEC_WARM_SLOTS > 0 && !EEC_WARM_PROD
         if (s == nslots - EEC_WARM_SLOTS) {
           // L2 warm-up for the stage boundary, in the consumers' slack: this workgroup's 1/32 share of what the next
           // phase streams (the next stage's weights, or the in_proj weights of the tail).  Without it the boundary
@@ -803,7 +834,7 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
         __syncthreads();
         TL_STAMP();  // consumer: barrier passed
       }
-#if EEC_WARM_SLOTS > 0
+#if EEC_WARM_SLOTS > 0 && !EEC_WARM_PROD
       sink ^= warm[0] ^ warm[1] ^ warm[2] ^ warm[3];
 #endif
 #if EEC_ROLL_WARM > 0
@@ -973,10 +1004,15 @@ hipError_t launch_ffn_chain_d<EEC_FFN_D>(const ChainArgs& a_in, int np, int np_f
   }
 #endif
   const int f = front ? np_front : 0, q = tail ? np_tail : 0;
-#ifdef EEC_CHAIN_MINIMAL  // tuning builds: only the three launches of the default (f16f8) production plan
+#ifdef EEC_CHAIN_MINIMAL  // tuning builds: only the three launches of the production plan in the default (f16x3) and the f16f8 mode
+  if (np == 3 && f == 0 && q == 3 && a.nstage == 1) return launch_chain_t<D, 3, 0, 0, 3, 1>(a, st);
+  if (np == 3 && f == 3 && q == 3 && a.nstage == 2) return launch_chain_t<D, 3, 0, 3, 3, 2>(a, st);
+  if (np == 3 && f == 3 && q == 0 && a.nstage == 1) return launch_chain_t<D, 3, 0, 3, 0, 1>(a, st);
+#ifdef EEC_CHAIN_MINIMAL_F8
   if (np == 8 && f == 0 && q == 8 && a.nstage == 1) return launch_chain_t<D, 8, 0, 0, 8, 1>(a, st);
   if (np == 8 && f == 8 && q == 8 && a.nstage == 2) return launch_chain_t<D, 8, 0, 8, 8, 2>(a, st);
   if (np == 8 && f == 8 && q == 0 && a.nstage == 1) return launch_chain_t<D, 8, 0, 8, 0, 1>(a, st);
+#endif
   return hipErrorInvalidValue;
 #else
 #define EEC_CHAIN_CASE(NP_, F_, Q_)                                                                      \

@@ -197,12 +197,14 @@ void ln_bwd(Run& r, const float* dln, const float* x, const float* g, const floa
 // the feed-forward module as one launch (a property of the configuration: the sizing pass carves the same way);
 // EEC_TRAIN_FFN_FUSED=0 keeps the LayerNorm + two-GEMM path (A/B runs, and what other geometries take)
 bool ffn_fused_fwd_supported(const eec_trainer* tr) {
-  static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED"); return e && atoi(e) == 0; }();
+  const char* e = getenv("EEC_TRAIN_FFN_FUSED");  // read per call: the tests flip it between steps of one process
+  const bool off = e && atoi(e) == 0;
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
   return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
 }
 bool ffn_fused_bwd_supported(const eec_trainer* tr) {
-  static const bool off = [] { const char* e = getenv("EEC_TRAIN_FFN_FUSED_BWD"); return e && atoi(e) == 0; }();
+  const char* e = getenv("EEC_TRAIN_FFN_FUSED_BWD");
+  const bool off = e && atoi(e) == 0;
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
   return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
 }

@@ -402,6 +402,49 @@ def test_dropout_masks_are_consistent_between_forward_and_backward(cfg):
         assert abs(fd - an) < 0.05 * max(abs(an), abs(fd)) + 2e-3, n
 
 
+def test_fused_feed_forward_equals_the_gemm_path_at_the_benchmark_shape():
+    """The feed-forward modules of the training step run as one launch per direction (csrc/ffn.hip TR variants); EEC_TRAIN_FFN_FUSED=0 /
+    EEC_TRAIN_FFN_FUSED_BWD=0 keep the LayerNorm + GEMM path of rounds 2-3.  Same seed -> same dropout masks on both paths, so the
+    two steps are comparable WITH dropout at a size the CPU oracle cannot reach: the default 12-layer model, d_ff 2048, T = 1027,
+    ragged lengths, 16 utterances.  Forward on fp16 pairs vs bf16 pairs and a different summation order: log-probs within 2e-4,
+    every gradient within 2e-3 of its largest entry."""
+    import os
+    kw = base_kwargs()
+    _, gpu = make_train_pair(kw, seed=77, drop=0.1)
+    B, T = 16, 1027
+    mel = synth.synth_mel(B, 80, T, seed=77).cuda()
+    lens = torch.tensor([1027, 1027, 1000, 903, 771, 642, 515, 400, 1027, 259, 131, 99, 64, 47, 31, 31])
+    tgt, tl = synth.synth_targets(B, 3, kw["dec_voc_size"], seed=77)  # 3 tokens: feasible for the 6-frame utterances too
+
+    def step():
+        torch.manual_seed(3)
+        gpu.zero_grad()
+        out = gpu(mel, lens)
+        loss = exit_ctc_losses(out, tgt, tl).sum()
+        loss.backward()
+        return out.detach().cpu(), loss.item(), {n: p.grad.detach().cpu().double() for n, p in gpu.named_parameters()}
+
+    saved = {k: os.environ.get(k) for k in ("EEC_TRAIN_FFN_FUSED", "EEC_TRAIN_FFN_FUSED_BWD")}
+    try:
+        os.environ.pop("EEC_TRAIN_FFN_FUSED", None), os.environ.pop("EEC_TRAIN_FFN_FUSED_BWD", None)
+        o_f, l_f, g_f = step()
+        os.environ["EEC_TRAIN_FFN_FUSED"] = "0"
+        os.environ["EEC_TRAIN_FFN_FUSED_BWD"] = "0"
+        o_g, l_g, g_g = step()
+        os.environ["EEC_TRAIN_FFN_FUSED"] = "1"  # fused forward, GEMM-path backward: the tape the fused forward writes is the GEMM path's
+        o_m, l_m, g_m = step()
+    finally:
+        for k, v in saved.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    assert torch.isfinite(o_f).all() and not torch.equal(o_f, o_g)  # two different code paths did run
+    err = (o_f - o_g).abs().max().item()
+    print(f"\n[fused vs GEMM path, dropout 0.1] max |dlogp| {err:.2e}; losses {l_f:.6f} / {l_g:.6f}")
+    assert err < 2e-4 and abs(l_f - l_g) < 2e-4 * abs(l_g)
+    assert torch.equal(o_m, o_f)
+    compare_grads(g_f, g_g, 2e-3, "fused feed-forward vs GEMM path")
+    compare_grads(g_m, g_g, 2e-3, "fused forward + GEMM-path backward vs GEMM path")
+
+
 def test_train_mode_without_autograd_keeps_train_semantics():
     """model.train() under torch.no_grad() (the reference would still use batch statistics and dropout): same output as the
     autograd forward with the same seed, different from eval mode."""
