@@ -32,6 +32,21 @@ struct DropState {
   __device__ __forceinline__ float mul(uint64_t i) const { return !on ? 1.0f : (drop_keep(key, i, thr) ? inv_keep : 0.0f); }
   // the multipliers of elements i .. i + 3 (the same values as mul(i + j)): the index products of the hash are shared -- h(i + j) =
   // h(i) + j * C1 (+ C2 when the low word wraps) -- so four elements cost 10 quarter-rate 32-bit multiplies instead of 16
+  // ... and of elements i, i + stride, i + 2 stride, i + 3 stride (3 * stride < 2^32): the attention kernels that hold a key per lane walk
+  // the virtual [B H, T', T'] tensor down a column
+  __device__ __forceinline__ void mul4s(uint64_t i, uint32_t stride, float (&m)[4]) const {
+    if (!on) {
+      m[0] = m[1] = m[2] = m[3] = 1.0f;
+      return;
+    }
+    const uint32_t lo = (uint32_t)i, h0 = lo * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + key, s1 = stride * 0x9E3779B1u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t h = h0 + (uint32_t)j * s1 + ((lo + (uint32_t)j * stride) < lo ? 0x85EBCA77u : 0u);
+      h ^= h >> 16, h *= 0x7FEB352Du, h ^= h >> 15, h *= 0x846CA68Bu, h ^= h >> 16;
+      m[j] = h >= thr ? inv_keep : 0.0f;
+    }
+  }
   __device__ __forceinline__ void mul4(uint64_t i, float (&m)[4]) const {
     if (!on) {
       m[0] = m[1] = m[2] = m[3] = 1.0f;

@@ -8,7 +8,7 @@
 // their rows, so that an accumulator lane already holds what the next MFMA wants as its operand: accumulator register i
 // of lane half h is tile row 16*(i/8) + 8*((i%8)/4) + 4*h + i%4, i.e. registers 8*ks .. 8*ks+7 are the eight k-slots of
 // k-step ks; the partner operand is gathered from memory with the same slot -> row map.
-#include "eec_train.h"
+#include "eec_drop.h"
 
 namespace eec {
 hipError_t ensure_max_lds(const void* kernel, int bytes);  // pack.hip: per-device MaxDynamicSharedMemorySize attribute
@@ -23,27 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-struct DropState2 {  // same generator as train_kernels.hip (kept in sync by tests: fused and unfused paths must agree)
-  uint32_t key, thr;
-  float inv_keep;
-  bool on;
-  __device__ __forceinline__ explicit DropState2(const Drop& d) {
-    uint64_t x = d.seed * 0x9E3779B97F4A7C15ull + ((uint64_t)d.site << 32 | d.site);
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    key = (uint32_t)(x >> 32) ^ (uint32_t)x;
-    const double t = (double)d.p * 4294967296.0;
-    thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
-    inv_keep = d.p > 0.0f ? 1.0f / (1.0f - d.p) : 1.0f;
-    on = d.p > 0.0f;
-  }
-  __device__ __forceinline__ float mul(uint64_t i) const {
-    if (!on) return 1.0f;
-    uint32_t h = (uint32_t)i * 0x9E3779B1u + (uint32_t)(i >> 32) * 0x85EBCA77u + key;
-    h ^= h >> 16, h *= 0x7FEB352Du, h ^= h >> 15, h *= 0x846CA68Bu, h ^= h >> 16;
-    return h >= thr ? inv_keep : 0.0f;
-  }
-};
+typedef DropState DropState2;  // the training step's generator (eec_drop.h)
 
 struct Frag {
   bf16x8 hi, lo;
@@ -254,11 +234,16 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
     float psum = 0.0f;
     f32x16 pd;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key = kt * 32 + acc_row(i, hh);
-      const float p = key < g.len ? __expf(sc[i] - m_new) : 0.0f;
-      psum += p;
-      pd[i] = p * ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
+    for (int gk = 0; gk < 4; ++gk) {  // register quad gk = four consecutive keys: one set of index products for their four masks
+      float dm[4];
+      ds.mul4((uint64_t)(g.pbase + (long)q * Tq + kt * 32 + 8 * gk + 4 * hh), dm);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * gk + e, key = kt * 32 + acc_row(i, hh);
+        const float p = key < g.len ? __expf(sc[i] - m_new) : 0.0f;
+        psum += p;
+        pd[i] = p * dm[e];
+      }
     }
     l_run = l_run * alpha + psum;
     Frag pf[2];
@@ -366,10 +351,15 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
     }
     f32x16 dsv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int key = kt * 32 + acc_row(i, hh);
-      const float p = (key < g.len && q < Tq) ? __expf(sc[i] * scale - lse_q) : 0.0f;
-      dsv[i] = scale * p * (dp[i] * ds.mul((uint64_t)(g.pbase + (long)q * Tq + key)) - del_q);
+    for (int gk = 0; gk < 4; ++gk) {
+      float dm[4];
+      ds.mul4((uint64_t)(g.pbase + (long)q * Tq + kt * 32 + 8 * gk + 4 * hh), dm);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * gk + e, key = kt * 32 + acc_row(i, hh);
+        const float p = (key < g.len && q < Tq) ? __expf(sc[i] * scale - lse_q) : 0.0f;
+        dsv[i] = scale * p * (dp[i] * dm[e] - del_q);
+      }
     }
     Frag dsf[2];
     dsf[0] = acc_frag<NP>(dsv, 0), dsf[1] = acc_frag<NP>(dsv, 1);
@@ -465,13 +455,17 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(con
     }
     f32x16 pdv, dsv;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int q = qt * 32 + acc_row(i, hh);
-      const bool ok = live && q < Tq;
-      const float p = ok ? __expf(sc[i] * scale - lse_r[i]) : 0.0f;
-      const float m = ds.mul((uint64_t)(g.pbase + (long)q * Tq + key));
-      pdv[i] = p * m;
-      dsv[i] = scale * p * (dp[i] * m - del_r[i]);
+    for (int gq = 0; gq < 4; ++gq) {  // register quad gq = four consecutive queries of this lane's key: indices Tq apart
+      float dm[4];
+      ds.mul4s((uint64_t)(g.pbase + (long)(qt * 32 + 8 * gq + 4 * hh) * Tq + key), (uint32_t)Tq, dm);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = 4 * gq + e, q = qt * 32 + acc_row(i, hh);
+        const bool ok = live && q < Tq;
+        const float p = ok ? __expf(sc[i] * scale - lse_r[i]) : 0.0f;
+        pdv[i] = p * dm[e];
+        dsv[i] = scale * p * (dp[i] * dm[e] - del_r[i]);
+      }
     }
     Frag pdf[2], dsf[2];
     pdf[0] = acc_frag<NP>(pdv, 0), pdf[1] = acc_frag<NP>(pdv, 1), dsf[0] = acc_frag<NP>(dsv, 0), dsf[1] = acc_frag<NP>(dsv, 1);
