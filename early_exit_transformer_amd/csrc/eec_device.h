@@ -457,6 +457,11 @@ __device__ __forceinline__ void gemm_plain_ring(f32x16 (&acc)[2][NT], const char
 #ifndef EEC_MFMA16
 #define EEC_MFMA16 1
 #endif
+// (a translation-unit switch, off: the single-product format on the 16x16x32 shape too -- slower in the inference kernels; an experiment of
+// the training step's fused feed-forward, whose tape stores want the quadrant layout's 16 rows x 64 B per instruction)
+#ifndef EEC_MFMA16_NP1
+#define EEC_MFMA16_NP1 0
+#endif
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 mfma32(h8 a, h8 b, f32x4 c) {
 #if EEC_OPERAND_BF16
@@ -715,7 +720,7 @@ __device__ __forceinline__ void gemm_plain_16(f32x16 (&acc)[MT][NT], const char*
 // vector issue for 8 of its 16 cycles instead of 8 of 32 (measured: `mixed` 27.0 -> 22.9 M, `f16` 30.3 -> 23.9 M frames/s).
 // IN_STD / OUT_STD only matter for the 16x16x32 forms (the 32x32x16 accumulators are always in the standard layout).
 template <int NP>
-constexpr bool kMfma16For = (EEC_MFMA16 != 0) && NP == 3;
+constexpr bool kMfma16For = (EEC_MFMA16 != 0) && (NP == 3 || (EEC_MFMA16_NP1 != 0 && NP == 1));
 template <int NP, int PF, int NT>
 __device__ __forceinline__ void ring_fill(WRing<NP, PF, NT>& r, const uint4* __restrict__ w_lane, size_t nt_stride, int steps_avail) {
   if constexpr (kMfma16For<NP>) ring_fill_16<NP, PF, NT>(r, w_lane, nt_stride, steps_avail);

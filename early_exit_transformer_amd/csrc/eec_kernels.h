@@ -148,7 +148,7 @@ struct ChainArgs {
   ChainTrain tr;    // TR variants only
 };
 // the feed-forward module of the training step's forward as one launch (plain-domain SiLU, weights packed with scale 1);
-// np = 3 (the split format) only; d_model 256 / 512, F % 32 == 0
+// np 3 (split pairs) or 1 (single fp16 / bf16 operands); d_model 256 / 512, F % 32 == 0
 hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st);
 // ... and the data path of its backward as one launch: x = the gradient of the module's output [M][D]; dh = st[0].res_scale *
 // dropmask(site_res) * x is what gets multiplied, and is stored to tr.ln (the operand of the W2 / b2 gradient); st[0].w1p = W2^T as

@@ -30,6 +30,11 @@
 #ifdef EEC_FFN_TRAIN_BWD  // fourth object of this source: the backward variants, on bf16 operands (see eec_device.h)
 #define EEC_OPERAND_BF16 1
 #endif
+#if defined(EEC_FFN_TRAIN) || defined(EEC_FFN_TRAIN_BWD)
+// the training variants' single-product form runs on the 16x16x32 shape as well: its accumulator layout stores 16 rows x 64 B per
+// instruction to the tape; the 32x32 layout's 32 rows x 32 B make the same launch 417 instead of 88 us (profiles/r04_micro_ffn_train_fwd.txt)
+#define EEC_MFMA16_NP1 1
+#endif
 #include "eec_blocks.h"
 #include "eec_drop.h"
 
@@ -961,20 +966,20 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
 #if defined(EEC_FFN_TRAIN_BWD)
 // Fourth object of this source (build/ffn_train_bwd.o, bf16 operands): the training step's backward variants.
 hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st) {
-  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || np != 3) return hipErrorInvalidValue;
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
   if (!a.tr.y || !a.tr.pre || !a.tr.act || !a.tr.ln) return hipErrorInvalidValue;
-  if (a.D == 256) return launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st);
-  if (a.D == 512) return launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st);
+  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 2>(a, st);
+  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 2>(a, st);
   return hipErrorInvalidValue;
 }
 }  // namespace eec
 #elif defined(EEC_FFN_TRAIN)
 // Third object of this source (build/ffn_train.o): only the training step's forward variants.
 hipError_t launch_ffn_train_fwd(const ChainArgs& a, int np, hipStream_t st) {
-  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || np != 3) return hipErrorInvalidValue;
+  if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
   if (!a.tr.y || !a.tr.ln || !a.tr.mean || !a.tr.rstd || !a.tr.pre || !a.tr.act) return hipErrorInvalidValue;
-  if (a.D == 256) return launch_chain_t<256, 3, 2, 0, 0, 1, 1>(a, st);
-  if (a.D == 512) return launch_chain_t<512, 3, 2, 0, 0, 1, 1>(a, st);
+  if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 1>(a, st);
+  if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 1>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 1>(a, st);
   return hipErrorInvalidValue;
 }
 }  // namespace eec

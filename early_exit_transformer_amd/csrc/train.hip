@@ -200,13 +200,13 @@ bool ffn_fused_fwd_supported(const eec_trainer* tr) {
   const char* e = getenv("EEC_TRAIN_FFN_FUSED");  // read per call: the tests flip it between steps of one process
   const bool off = e && atoi(e) == 0;
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
-  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
 }
 bool ffn_fused_bwd_supported(const eec_trainer* tr) {
   const char* e = getenv("EEC_TRAIN_FFN_FUSED_BWD");
   const bool off = e && atoi(e) == 0;
   const int D = tr->cfg.d_model, F = tr->cfg.d_ff;
-  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && tr->np == 3;  // single-product mode: the fused variants are VALU-bound there (389 / 231 us per launch) -- GEMM path
+  return !off && (D == 256 || D == 512) && F >= 32 && F % 32 == 0 && (tr->np == 1 || tr->np == 3);
 }
 // Room for the fragment images of every feed-forward module's W1 / W2 (4 x F x D x 4 bytes per module), carved from the tape at the
 // start of a forward by geometry alone (the tape layout must not depend on the operand mode of a particular step); a module's images
