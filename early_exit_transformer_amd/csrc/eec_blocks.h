@@ -13,6 +13,9 @@ constexpr int kLinLds = 2 * Geo<D>::kAPlane;  // the activation planes only
 #endif
 constexpr int kLPF = EEC_LPF;  // weight fragments (1 KiB each per plane) a wave keeps in flight per column tile
 
+// per-wave LDS staging of qkv_body's whole-line stores: [64 frames][80 B] for Q / K, [32 dims][144 B] for V^T (rows padded by 16 B)
+constexpr int kQkvStageLd = 80, kQkvStageLdV = 144, kQkvStageBytes = 64 * kQkvStageLd;
+static_assert(32 * kQkvStageLdV <= kQkvStageBytes, "V^T staging fits the Q / K staging area");
 __device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-order of an accumulator-fed operand
   return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
 }
@@ -122,11 +125,57 @@ __device__ __forceinline__ void proj_gemm(f32x16 (&acc)[MT][NT], const char* sme
 // k-steps of this wave's Q weight tiles (filled by the caller, ahead of time).  Wave w owns output columns
 // [32 NW w, 32 NW (w + 1)) of each of Q, K, V.  (the in_proj of nn.MultiheadAttention.)
 template <int D, int NP>
-__device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0, ProjStream<NP, kLPF, Geo<D>::kNW>& rq) {
+__device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0, ProjStream<NP, kLPF, Geo<D>::kNW>& rq, char* stage = nullptr) {
   using G = Geo<D>;
   constexpr int MT = G::kMT, NW = G::kNW;
   const int lane = lane_id(), w = wave_id(), hh = lane >> 5;
   const int dh = D / a.H;
+  // Whole-line stores (d_model 256, 8 heads, T' a multiple of the 64-row tile, `stage` = kQkvStageBytes of LDS per wave): a wave owns one
+  // head, its 64 frames x 32 dims of Q (and K) are one contiguous 4 KB block per plane and its V^T block is 32 rows of 128 B -- the
+  // accumulator tile is transposed through the wave's own staging area and leaves as 16-byte stores of consecutive lanes (1 KB
+  // contiguous per instruction for Q / K, 8 rows x 128 B for V^T) instead of 8-byte pieces of 32 rows (Q, K) and 2-byte stores (V^T):
+  // the stores cost 8 us of a 216 us chain launch before (same-box ablation, profiles/r04_ab_qkv_stores.txt)
+  const bool fast = D == 256 && stage != nullptr && dh == 32 && a.Tq % G::kRows == 0 && a.Tp == a.Tq;  // uniform
+  char* const stg = stage ? stage + w * kQkvStageBytes : nullptr;
+  // hi / lo halves of a finished [64 frames][32 dims] accumulator tile -> the two planes at element offset `off` (frame-major rows of 32)
+  [[maybe_unused]] auto store_rows_fast = [&](const f32x16 (&acc)[MT][NW], float scale, half_t* p_hi, half_t* p_lo, size_t off) {
+    h4 lo4[MT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = acc[mt][0][4 * g + i] * scale;
+          o[i] = to_half_sat(v);
+          lo4[mt][g][i] = (half_t)(v - (float)o[i]);
+        }
+        *(h4*)(stg + (mt * 32 + (lane & 31)) * kQkvStageLd + (8 * g + 4 * hh) * 2) = o;
+      }
+    // the staging area is the wave's own and the LDS serves a wave's accesses in order: no barrier, but the COMPILER must keep the
+    // accesses of different types in program order
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int row = (lane >> 2) + 16 * k;
+      *(uint4*)(p_hi + off + (size_t)row * 32 + (lane & 3) * 8) = *(const uint4*)(stg + row * kQkvStageLd + (lane & 3) * 16);
+    }
+    asm volatile("" ::: "memory");
+    if (p_lo) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *(h4*)(stg + (mt * 32 + (lane & 31)) * kQkvStageLd + (8 * g + 4 * hh) * 2) = lo4[mt][g];
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int row = (lane >> 2) + 16 * k;
+        *(uint4*)(p_lo + off + (size_t)row * 32 + (lane & 3) * 8) = *(const uint4*)(stg + row * kQkvStageLd + (lane & 3) * 16);
+      }
+      asm volatile("" ::: "memory");
+    }
+  };
   const WMat wm{a.wp, a.wf8};
   ProjStream<NP, kLPF, NW> rk;
   // row -> (utterance, frame) of this lane's frames
@@ -155,7 +204,12 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
   acc_init_bias_np<NP, MT, NW>(acc, a.bias + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, t0);
   proj_fill<D, NP, kLPF, NW>(rq, wm, 2 * TQ + t0);  // V weights, in flight during the K pass
-  {
+  if (fast) {
+    if constexpr (D == 256) {
+      const int b0 = row0 / a.Tq, tt0 = row0 - b0 * a.Tq;
+      store_rows_fast(acc, kLog2e * rsqrtf((float)dh), a.q, a.q_lo, ((size_t)(b0 * a.H + w) * a.Tp + tt0) * 32);
+    }
+  } else {
     const float scale = kLog2e * rsqrtf((float)dh);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -182,6 +236,12 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
   // ---- K ----
   acc_init_bias_np<NP, MT, NW>(acc, a.bias + D + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rk, wm, TQ + t0);
+  if (fast) {
+    if constexpr (D == 256) {
+      const int b0 = row0 / a.Tq, tt0 = row0 - b0 * a.Tq;
+      store_rows_fast(acc, 1.0f, a.k, a.k_lo, ((size_t)(b0 * a.H + w) * a.Tp + tt0) * 32);
+    }
+  } else
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     if (ok[mt]) {
@@ -206,6 +266,36 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
   // ---- V: V^T[b][h][d][perm(t)], 2-byte stores contiguous along t ----
   acc_init_bias_np<NP, MT, NW>(acc, a.bias + 2 * D + 32 * t0);
   proj_gemm<D, NP, kLPF, NW, MT>(acc, smem, rq, wm, 2 * TQ + t0);
+  if (fast) {
+    if constexpr (D == 256) {
+      // V^T[b][h][d][perm(t)]: the tile's 64 frames are 128 contiguous bytes of each of the head's 32 rows d
+      const int b0 = row0 / a.Tq, tt0 = row0 - b0 * a.Tq;
+      const size_t vbase = ((size_t)(b0 * a.H + w) * 32) * a.Tp + tt0;
+      auto plane = [&](half_t* dstp, bool lo_plane) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int tcol = vt_perm(mt * 32 + (lane & 31));
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float v = acc[mt][0][4 * g + i];
+              const half_t hi = to_half_sat(v);
+              *(half_t*)(stg + (8 * g + 4 * hh + i) * kQkvStageLdV + tcol * 2) = lo_plane ? (half_t)(v - (float)hi) : hi;
+            }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = (lane >> 3) + 8 * k;
+          *(uint4*)(dstp + vbase + (size_t)d * a.Tp + (lane & 7) * 8) = *(const uint4*)(stg + d * kQkvStageLdV + (lane & 7) * 16);
+        }
+        asm volatile("" ::: "memory");
+      };
+      plane(a.vt, false);
+      if (a.vt_lo) plane(a.vt_lo, true);
+    }
+  } else
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
     if (ok[mt]) {

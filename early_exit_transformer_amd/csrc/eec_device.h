@@ -53,6 +53,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 // non-temporal hint, so that they do not push the weight streams out of the L2.  NT = a compile-time flag per site.
 template <bool NT, typename T>
 __device__ __forceinline__ void store_maybe_nt(T* p, T v) {
+#ifdef EEC_ABLATE_QKV_STORES  // timing-only build: what the Q / K / V / GLU / head stores cost (the value stays live, nothing is written)
+  asm volatile("" ::"v"(v), "v"(p));
+  return;
+#endif
   if constexpr (NT) __builtin_nontemporal_store(v, p);
   else *p = v;
 }

@@ -924,7 +924,9 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     if (more || QNP != 0) __syncthreads();  // next planes complete; the exchange tile is free again
     TL_STAMP();  // stage epilogue + row pass done
   });
-  if constexpr (QNP != 0) qkv_body<D, QNP>(smem, a.qkv, row0, rq);
+  // (the H buffers are dead by now: 8 x 5 KB of them stage the tail's whole-line Q / K / V^T stores)
+  static_assert(QNP == 0 || 8 * kQkvStageBytes <= 4 * FG::kHPlane || D != 256, "qkv staging fits the H buffers");
+  if constexpr (QNP != 0) qkv_body<D, QNP>(smem, a.qkv, row0, rq, D == 256 ? lds_h : nullptr);
   if ((sink ^ sink_front) == 0x9e3779b9u && M == -7) x[0] = 0.f;  // never true: the warm-up loads must not be optimised away
   TL_STAMP();  // last: epilogue done
   };
