@@ -433,6 +433,32 @@ __global__ __launch_bounds__(kLinThreads, 2) void proj_glu_kernel(ProjResArgs a,
   acc_init_bias_np<NP, MT, NW>(ag, gl.bias + D + 32 * NW * w);
   proj_gemm<D, NP, kLPF, NW, MT>(ag, smem, rg, wg, TQ + NW * w);
   EEC_TL_STAMP(glu, 9);
+  if constexpr (D == 256) {
+    // the wave's [64 rows][32 columns] of GLU output through its own staging area (the exchange tile is dead by now): 16 rows x 64 B
+    // per store instruction instead of 32 rows x 16 B (see qkv_body's whole-line stores, eec_blocks.h)
+    char* const stg = lds_e + w * kQkvStageBytes;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        h4 o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float gate = ag[mt][0][4 * g + i];
+          o[i] = to_half_sat(av[mt][0][4 * g + i] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-kLog2e * gate)));
+        }
+        *(h4*)(stg + (mt * 32 + (lane & 31)) * kQkvStageLd + (8 * g + 4 * hh) * 2) = o;
+      }
+    asm volatile("" ::: "memory");  // the wave's own area, served in order: only the compiler has to keep the order
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rl = (lane >> 2) + 16 * k;
+      const uint4 v = *(const uint4*)(stg + rl * kQkvStageLd + (lane & 3) * 16);
+      if (row0 + rl < a.M) *(uint4*)(gl.g + (size_t)(row0 + rl) * D + 32 * w + (lane & 3) * 8) = v;
+    }
+    EEC_TL_STAMP(glu, 10);
+    return;
+  }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int row = row0 + mt * 32 + (lane & 31);
