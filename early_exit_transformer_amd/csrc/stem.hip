@@ -14,6 +14,8 @@
 // each, and rescales the accumulators (lane = output frame) by 2^(e_j - e_(j+1)) between the passes.  One outlier bin or
 // one loud utterance therefore costs no other frame its precision, and nothing saturates up to fp32's own range.
 #include "eec_kernels.h"
+#include <algorithm>
+
 #include "eec_blocks.h"
 
 namespace eec {
@@ -34,6 +36,10 @@ __device__ __forceinline__ int row_exponent(float m) {
 // conv1.  K1 = n_mels * 3 (multiple of 16, <= 384); plane row stride (K1 + 8) halves.
 // DIRECT: the one-convolution stem of Early_zipformer (Conv1dSubampling_Zipformer, early_exit.py:80-95): the result
 // leaves as fp32 x[b][t1][:] = conv + bias + pe[t1] instead of the scaled fp16 planes that feed conv2.
+// where the staged output tile of conv1 starts: inside the (dead) input planes when they hold it, else behind the row maxima
+__host__ __device__ constexpr int stem1_stage_offset(int planes_bytes, int stage_bytes) {
+  return planes_bytes >= stage_bytes ? 0 : (planes_bytes + 2 * kStemRows1 * 4 + 15) / 16 * 16;
+}
 template <int D, int NP, bool DIRECT>
 __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleArgs a) {
   constexpr int NW = Geo<D>::kNW;
@@ -149,28 +155,49 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv1_kernel(SubsampleAr
     atomicMax(&out_max[mt * 32 + (lane & 31)], __builtin_bit_cast(unsigned, m));
   }
   __syncthreads();
-  // mid planes [B*T1][D]: lane = row, register quad = 4 consecutive channels; mid_e[row] = exponent of the row's domain
+  // mid planes [B*T1][D]: lane = row, register quad = 4 consecutive channels; mid_e[row] = exponent of the row's domain.
+  // The tile leaves through LDS (the input planes are dead; the staging area sits in them, or behind the row maxima when they are
+  // too small): straight from the accumulators a store instruction is 32 rows x 16 B, from the staged tile it is 8 KB of whole rows.
+  constexpr int kSLd = D * 2 + 16;  // staged row stride (bytes)
+  char* const stg = smem + stem1_stage_offset(2 * plane, kStemRows1 * kSLd);
+  h4 lo4[2][NW][4];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int row = rowl[mt];
-    if (row < M1) {
-      const int eo = row_exponent(__builtin_bit_cast(float, out_max[mt * 32 + (lane & 31)]));  // relative to the input domain
-      if (w == 0 && hh == 0) a.mid_e[row] = el[mt] + eo;
-      const float sc = ldexpf(1.0f, -eo);
+    const int eo = row_exponent(__builtin_bit_cast(float, out_max[mt * 32 + (lane & 31)]));  // relative to the input domain
+    if (row < M1 && w == 0 && hh == 0) a.mid_e[row] = el[mt] + eo;
+    const float sc = ldexpf(1.0f, -eo);
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) {
-        const size_t off = (size_t)row * D + 32 * (NW * w + nt) + 4 * hh;
+    for (int nt = 0; nt < NW; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const hl2_t s0 = split2<NP>(acc[mt][nt][4 * g + 0] * sc, acc[mt][nt][4 * g + 1] * sc);
-          const hl2_t s1 = split2<NP>(acc[mt][nt][4 * g + 2] * sc, acc[mt][nt][4 * g + 3] * sc);
-          h4 hi, lo;
-          hi.xy = s0.hi, hi.zw = s1.hi, lo.xy = s0.lo, lo.zw = s1.lo;
-          *(h4*)(a.mid_hi + off + 8 * g) = hi;
-          if (NP == 3) *(h4*)(a.mid_lo + off + 8 * g) = lo;
-        }
+      for (int g = 0; g < 4; ++g) {
+        const hl2_t s0 = split2<NP>(acc[mt][nt][4 * g + 0] * sc, acc[mt][nt][4 * g + 1] * sc);
+        const hl2_t s1 = split2<NP>(acc[mt][nt][4 * g + 2] * sc, acc[mt][nt][4 * g + 3] * sc);
+        h4 hi;
+        hi.xy = s0.hi, hi.zw = s1.hi, lo4[mt][nt][g].xy = s0.lo, lo4[mt][nt][g].zw = s1.lo;
+        *(h4*)(stg + (mt * 32 + (lane & 31)) * kSLd + (32 * (NW * w + nt) + 8 * g + 4 * hh) * 2) = hi;
       }
+  }
+  auto rows_out = [&](half_t* dstp) {
+    constexpr int PPR = D / 8;  // 16-byte pieces per row
+    for (int p = threadIdx.x; p < kStemRows1 * PPR; p += kStemThreads) {
+      const int rl = p / PPR, c16 = p - rl * PPR;
+      if (row0 + rl < M1) *(uint4*)(dstp + (size_t)(row0 + rl) * D + c16 * 8) = *(const uint4*)(stg + rl * kSLd + c16 * 16);
     }
+  };
+  __syncthreads();
+  rows_out(a.mid_hi);
+  if constexpr (NP == 3) {
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *(h4*)(stg + (mt * 32 + (lane & 31)) * kSLd + (32 * (NW * w + nt) + 8 * g + 4 * hh) * 2) = lo4[mt][nt][g];
+    __syncthreads();
+    rows_out(a.mid_lo);
   }
 }
 
@@ -253,23 +280,32 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv2_kernel(SubsampleAr
       }
     }
   }
+  // The fp32 tile leaves through LDS (the staged mid frames are dead once every wave is past its three passes): a wave then adds the
+  // positional encoding to, and stores, whole rows (1 KiB per instruction) -- from the accumulators a store instruction and a load of
+  // the encoding are 32 rows x 32 B each.
+  constexpr int kSLd2 = D * 4 + 16;
+  static_assert(G::kRows * kSLd2 <= S::kLds, "the staged output tile fits the input planes");
+  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int t = t0 + mt * 32 + (lane & 31);
+    const float up = ldexpf(1.0f, ej[mt][2]);
+#pragma unroll
+    for (int nt = 0; nt < NW; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *(float4*)(smem + (mt * 32 + (lane & 31)) * kSLd2 + (32 * (NW * w + nt) + 8 * g + 4 * hh) * 4) =
+            make_float4(acc[mt][nt][4 * g + 0] * up, acc[mt][nt][4 * g + 1] * up, acc[mt][nt][4 * g + 2] * up, acc[mt][nt][4 * g + 3] * up);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < G::kRPW; ++i) {
+    const int rl = w * G::kRPW + i, t = t0 + rl;
     if (t < a.Tq) {
-      const float up = ldexpf(1.0f, ej[mt][2]);
+      RowV<G::kQ> v = load_row<D>((const float*)(smem + rl * kSLd2), lane);
+      const RowV<G::kQ> p = load_row<D>(a.pe + (size_t)t * D, lane);
 #pragma unroll
-      for (int nt = 0; nt < NW; ++nt) {
-        const int c0 = 32 * (NW * w + nt) + 4 * hh;
-        float* dst = a.x + ((size_t)b * a.Tq + t) * D + c0;
-        const float* pe = a.pe + (size_t)t * D + c0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float4 p = *(const float4*)(pe + 8 * g);
-          *(float4*)(dst + 8 * g) = make_float4(acc[mt][nt][4 * g + 0] * up + p.x, acc[mt][nt][4 * g + 1] * up + p.y,
-                                                acc[mt][nt][4 * g + 2] * up + p.z, acc[mt][nt][4 * g + 3] * up + p.w);
-        }
-      }
+      for (int q = 0; q < G::kQ; ++q) v.p[q].x += p.p[q].x, v.p[q].y += p.p[q].y, v.p[q].z += p.p[q].z, v.p[q].w += p.p[q].w;
+      store_row<D>(a.x + ((size_t)b * a.Tq + t) * D, v, lane);
     }
   }
 }
@@ -277,10 +313,13 @@ __global__ __launch_bounds__(kStemThreads, 2) void stem_conv2_kernel(SubsampleAr
 template <int D>
 static hipError_t launch_subsample_d(const SubsampleArgs& a, int np, hipStream_t st) {
   const int K1 = a.n_mels * 3;
-  const int lds1 = 2 * kStemRows1 * (K1 + 8) * 2 + 2 * kStemRows1 * 4;
+  // input planes + row maxima, and the staged output tile (inside the planes when they are large enough, behind the maxima otherwise)
+  constexpr int kStage = kStemRows1 * (D * 2 + 16);
+  const int planes = 2 * kStemRows1 * (K1 + 8) * 2;
+  const int lds1 = std::max(planes + 2 * kStemRows1 * 4, stem1_stage_offset(planes, kStage) + kStage);
   auto k1 = np == 3 ? stem_conv1_kernel<D, 3, false> : stem_conv1_kernel<D, 1, false>;
   auto k2 = np == 3 ? stem_conv2_kernel<D, 3> : stem_conv2_kernel<D, 1>;
-  if (hipError_t e = ensure_max_lds((const void*)k1, 2 * kStemRows1 * (384 + 8) * 2 + 2 * kStemRows1 * 4); e != hipSuccess) return e;
+  if (hipError_t e = ensure_max_lds((const void*)k1, std::max(2 * kStemRows1 * (384 + 8) * 2 + 2 * kStemRows1 * 4, 2 * kStage + 1024)); e != hipSuccess) return e;
   if (hipError_t e = ensure_max_lds((const void*)k2, Stem2Geo<D>::kLds); e != hipSuccess) return e;
   const int M1 = a.B * a.T1;
   hipLaunchKernelGGL(k1, dim3((M1 + kStemRows1 - 1) / kStemRows1), dim3(kStemThreads), lds1, st, a);

@@ -32,7 +32,8 @@ with torch.no_grad():
     prof = m.read_profile()
 ts.sort()
 print(json.dumps({"fwd_ms": ts[len(ts) // 2] * 1e3, "chain_us": prof["chain"][0] / max(prof["chain"][1], 1) * 1e3,
-                  "glu_us": prof["proj_glu"][0] / max(prof["proj_glu"][1], 1) * 1e3, "attn_us": prof["attn"][0] / max(prof["attn"][1], 1) * 1e3}))
+                  "glu_us": prof["proj_glu"][0] / max(prof["proj_glu"][1], 1) * 1e3, "attn_us": prof["attn"][0] / max(prof["attn"][1], 1) * 1e3,
+                  "other_us": {k: round(v[0] / max(v[1], 1) * 1e3, 1) for k, v in prof.items() if k not in ("chain", "proj_glu", "attn") and v[1]}}))
 '''
 
 
@@ -60,7 +61,8 @@ def main():
             f = [x["fwd_ms"] for x in rs]
             c = [x["chain_us"] for x in rs]
             print(f"{n:12s} fwd ms median {statistics.median(f):.3f} min {min(f):.3f} | chain us median {statistics.median(c):.1f} min {min(c):.1f}"
-                  f" | glu {statistics.median([x['glu_us'] for x in rs]):.1f} attn {statistics.median([x['attn_us'] for x in rs]):.1f}", flush=True)
+                  f" | glu {statistics.median([x['glu_us'] for x in rs]):.1f} attn {statistics.median([x['attn_us'] for x in rs]):.1f}"
+                  f" | other {rs[-1].get('other_us')}", flush=True)
 
 
 if __name__ == "__main__":
