@@ -21,6 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef EECT_ABLATE_ATTN_STORES
+#define EECT_ABLATE_ATTN_STORES 0  // timing-only builds: 1 = the output tiles are computed and not stored
+#endif
 namespace {
 
 typedef DropState DropState2;  // the training step's generator (eec_drop.h)
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = g.len > 0 ? 1.0f / l_tot : NAN;  // no key at all: nan, as torch's masked softmax
-  if (q < Tq) {
+  if (q < Tq && !(EECT_ABLATE_ATTN_STORES && H > 0)) {
     float* dst = ctx + ((long)(z / H) * Tq + q) * D + (z % H) * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
     }
     __syncthreads();
   }
-  if (q < Tq) {
+  if (q < Tq && !(EECT_ABLATE_ATTN_STORES && H > 0)) {
     float* dst = dqkv + ((long)(z / H) * Tq + q) * 3 * D + (z % H) * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(con
     }
     __syncthreads();
   }
-  if (key < Tq) {
+  if (key < Tq && !(EECT_ABLATE_ATTN_STORES && H > 0)) {
     float* dst = dqkv + ((long)(z / H) * Tq + key) * 3 * D + (z % H) * DH;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
