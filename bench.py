@@ -546,7 +546,7 @@ def main():
     # WRITE_SIZE in separate passes, tools/pmc_passes.sh; FETCH_SIZE doubled: on gfx950 it reports half of a wide
     # coalesced read, MI355X_MICROARCH.md).  Static evidence, not re-measured here: PMC needs rocprofv3.
     PMC_EVIDENCE = {"f16f8": ("r03_c_pmc_chain_kernel_f16f8.txt", "ffn_chain_kernel<256, 8, 0, 8, 8, 2>"),
-                    "f16x3": ("r04_c_pmc_chain_kernel_f16x3.txt", "ffn_chain_kernel<256, 3, 0, 3, 3, 2>")}
+                    "f16x3": ("r04_d_pmc_chain_kernel_f16x3.txt", "ffn_chain_kernel<256, 3, 0, 3, 3, 2, 0>")}
     if roofline is not None and args.precision in PMC_EVIDENCE:
         pmc_file, pmc_kernel = PMC_EVIDENCE[args.precision]
         pmc = os.path.join(ROOT, "profiles", pmc_file)
