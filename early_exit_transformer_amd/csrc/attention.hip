@@ -259,6 +259,7 @@ static hipError_t launch_attn_t(const AttnArgs& a, hipStream_t st) {
 }
 
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st) {
+  if (a.vt_frag) return hipErrorInvalidValue;  // fragment-major V^T planes are the fused launch's (linear.hip)
   if (np == 3 && a.q_lo && a.k_lo && a.vt_lo) {  // exact mode
     if (a.dh == 32) return launch_attn_t<32, 3, true>(a, st);
     if (a.dh == 64) return launch_attn_t<64, 3, true>(a, st);

@@ -236,9 +236,15 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
                           TapFn tap_of, hipStream_t st) {
   const eec_config& c = enc->cfg;
   const int Tp = (Tq + 31) / 32 * 32, M = B * Tq, D = c.d_model, H = c.n_heads;
+  // the attention of a row tile runs in the prologue of the out_proj / GLU launch when the shape allows it -- a property of the
+  // call, not of the layer (exact mode: Q / K residual planes present -> its three-product form, which needs glu format 3); the
+  // chain tail then writes V^T fragment-major for it
+  AttnArgs at_shape{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
+  const bool fused_attn = attn_fusable(at_shape, D) && (np.att != 1) == (np.glu != 1) && (!b.q_lo || np.glu == 3);
   auto qkv_args = [&](const PackedLayer& L) {
     QkvArgs q{b.x, M, B, Tq, Tp, H, D, L.attn_ln_w, L.attn_ln_b, L.attn_in_p, L.attn_in_b, b.q, b.k, b.vt, b.vt_lo, L.attn_in_f8};
     q.q_lo = b.q_lo, q.k_lo = b.k_lo;
+    q.vt_frag = fused_attn && D == 256 && Tq % 64 == 0 ? 1 : 0;  // qkv_body's whole-line store path is taken for exactly these shapes
     return q;
   };
   auto stage1 = [&](const PackedLayer& L) {
@@ -257,10 +263,10 @@ static int run_layer_plan(eec_encoder* enc, int l0, int l1, const LayerBufs& b, 
     const bool last = li + 1 == l1;
     AttnArgs at{b.q, b.k, b.vt, b.key_len, B, H, Tq, Tp, D / H, b.p_hi, b.p_lo, b.vt_lo};
     at.q_lo = b.q_lo, at.k_lo = b.k_lo;
+    at.vt_frag = fused_attn && D == 256 && Tq % 64 == 0 ? 1 : 0;
     ProjResArgs pr{b.x, M, D, b.p_hi, b.p_lo, L.attn_out_p, L.attn_out_b, L.attn_out_f8};
     GluArgs ga{b.x, M, L.conv_ln_w, L.conv_ln_b, L.conv_pw1_p, L.conv_pw1_b, b.g, L.conv_pw1_f8};
-    // (exact mode: Q / K residual planes present -> the fused launch runs its three-product attention, which needs glu format 3)
-    if (attn_fusable(at, D) && (np.att != 1) == (np.glu != 1) && (!b.q_lo || np.glu == 3)) {
+    if (fused_attn) {
       // two launches per layer: the attention of a row tile runs in the prologue of the out_proj / GLU kernel
       TIMED(KC_PROJ_GLU, launch_attn_proj_glu(at, pr, ga, np.glu, st));
     } else {

@@ -16,6 +16,8 @@ constexpr int kLPF = EEC_LPF;  // weight fragments (1 KiB each per plane) a wave
 // per-wave LDS staging of qkv_body's whole-line stores: [64 frames][80 B] for Q / K, [32 dims][144 B] for V^T (rows padded by 16 B)
 constexpr int kQkvStageLd = 80, kQkvStageLdV = 144, kQkvStageBytes = 64 * kQkvStageLd;
 static_assert(32 * kQkvStageLdV <= kQkvStageBytes, "V^T staging fits the Q / K staging area");
+constexpr int kQkvFragLd = 1056;  // staged fragment stride (fragment-major V^T): 2 x (512 B + 16 B)
+static_assert(4 * kQkvFragLd <= kQkvStageBytes && (kQkvFragLd / 2) % 16 == 0, "fragment-major V^T staging");
 __device__ __forceinline__ int vt_perm(int t) {  // swap bits 2 and 3: MFMA k-order of an accumulator-fed operand
   return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1);
 }
@@ -156,11 +158,22 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
     // the staging area is the wave's own and the LDS serves a wave's accesses in order: no barrier, but the COMPILER must keep the
     // accesses of different types in program order
     asm volatile("" ::: "memory");
+    // the staged tile out: frame-major rows of 64 B, or (a.vt_frag) the four MFMA fragments of the tile -- (32-frame block j, 16 dims ks),
+    // lane (frame r, dim half hh) -- each 1 KiB contiguous; either way 4 KB contiguous at `off`
+    auto tile_out = [&](half_t* dstp) {
+      if (a.vt_frag) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int row = (lane >> 2) + 16 * k;
-      *(uint4*)(p_hi + off + (size_t)row * 32 + (lane & 3) * 8) = *(const uint4*)(stg + row * kQkvStageLd + (lane & 3) * 16);
-    }
+        for (int k = 0; k < 4; ++k)
+          *(uint4*)(dstp + off + k * 512 + lane * 8) = *(const uint4*)(stg + ((k >> 1) * 32 + (lane & 31)) * kQkvStageLd + (k & 1) * 32 + hh * 16);
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int row = (lane >> 2) + 16 * k;
+          *(uint4*)(dstp + off + (size_t)row * 32 + (lane & 3) * 8) = *(const uint4*)(stg + row * kQkvStageLd + (lane & 3) * 16);
+        }
+      }
+    };
+    tile_out(p_hi);
     asm volatile("" ::: "memory");
     if (p_lo) {
 #pragma unroll
@@ -168,11 +181,7 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
 #pragma unroll
         for (int g = 0; g < 4; ++g) *(h4*)(stg + (mt * 32 + (lane & 31)) * kQkvStageLd + (8 * g + 4 * hh) * 2) = lo4[mt][g];
       asm volatile("" ::: "memory");
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int row = (lane >> 2) + 16 * k;
-        *(uint4*)(p_lo + off + (size_t)row * 32 + (lane & 3) * 8) = *(const uint4*)(stg + row * kQkvStageLd + (lane & 3) * 16);
-      }
+      tile_out(p_lo);
       asm volatile("" ::: "memory");
     }
   };
@@ -271,24 +280,39 @@ __device__ __forceinline__ void qkv_body(char* smem, const QkvArgs& a, int row0,
       // V^T[b][h][d][perm(t)]: the tile's 64 frames are 128 contiguous bytes of each of the head's 32 rows d
       const int b0 = row0 / a.Tq, tt0 = row0 - b0 * a.Tq;
       const size_t vbase = ((size_t)(b0 * a.H + w) * 32) * a.Tp + tt0;
+      // staging offset of element (d, tcol) = base(tcol) + d * dstride in either layout: rows [d][tcol] (144-B rows), or fragment-major
+      // -- fragment (key tile tcol / 32, k-step (tcol / 16) % 2), lane d + 32 ((tcol / 8) % 2), element tcol % 8, staged with 16 B of
+      // padding per 512-B half fragment (the four pieces a store instruction touches would otherwise share their banks)
+      const int dstride = a.vt_frag ? 16 : kQkvStageLdV;
+      int sbase[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int tcol = vt_perm(mt * 32 + (lane & 31));
+        sbase[mt] = a.vt_frag ? ((tcol >> 5) * 2 + ((tcol >> 4) & 1)) * kQkvFragLd + ((tcol >> 3) & 1) * (kQkvFragLd / 2) + (tcol & 7) * 2 : tcol * 2;
+      }
       auto plane = [&](half_t* dstp, bool lo_plane) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const int tcol = vt_perm(mt * 32 + (lane & 31));
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const float v = acc[mt][0][4 * g + i];
               const half_t hi = to_half_sat(v);
-              *(half_t*)(stg + (8 * g + 4 * hh + i) * kQkvStageLdV + tcol * 2) = lo_plane ? (half_t)(v - (float)hi) : hi;
+              *(half_t*)(stg + sbase[mt] + (8 * g + 4 * hh + i) * dstride) = lo_plane ? (half_t)(v - (float)hi) : hi;
             }
-        }
         asm volatile("" ::: "memory");
+        if (a.vt_frag) {  // the tile's four fragments are 4 KB contiguous: [b][h][key tile][k-step][lane][8]
+          half_t* const fb = dstp + (size_t)(b0 * a.H + w) * 32 * a.Tp + (size_t)(tt0 >> 5) * 1024;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int d = (lane >> 3) + 8 * k;
-          *(uint4*)(dstp + vbase + (size_t)d * a.Tp + (lane & 7) * 8) = *(const uint4*)(stg + d * kQkvStageLdV + (lane & 7) * 16);
+          for (int k = 0; k < 4; ++k)
+            *(uint4*)(fb + k * 512 + lane * 8) = *(const uint4*)(stg + k * kQkvFragLd + (lane >> 5) * (kQkvFragLd / 2) + (lane & 31) * 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int d = (lane >> 3) + 8 * k;
+            *(uint4*)(dstp + vbase + (size_t)d * a.Tp + (lane & 7) * 8) = *(const uint4*)(stg + d * kQkvStageLdV + (lane & 7) * 16);
+          }
         }
         asm volatile("" ::: "memory");
       };

@@ -39,6 +39,10 @@ struct QkvArgs {
   half_t* vt_lo = nullptr;  // optional: fp16 residual V - fp16(V), same layout (the PV product then runs on hi + lo)
   const uint4* wf8 = nullptr;  // the same matrix as the f8 record stream (NP == 8)
   half_t *q_lo = nullptr, *k_lo = nullptr;  // optional (exact mode): fp16 residuals of the scaled Q and of K, same layouts
+  // 1: Q, K, V^T (and their residuals) fragment-major -- [b][h][block of 32 frames][k-step of 16][lane][8 halves], i.e. every MFMA fragment
+  // the fused attention reads (AttnArgs::vt_frag) is 1 KiB contiguous instead of 32 rows x 32 B.  Only the chain tail's whole-line store path
+  // writes it (d_model 256, 8 heads, T' % 64 == 0, see qkv_body); the plan sets it exactly when the fused launch consumes the planes.
+  int vt_frag = 0;
 };
 hipError_t launch_qkv(const QkvArgs& a, int np, hipStream_t st);
 
@@ -101,6 +105,7 @@ struct AttnArgs {
   const half_t* vt_lo = nullptr;  // optional residual plane of V^T (see QkvArgs)
   const half_t *q_lo = nullptr, *k_lo = nullptr;  // optional residual planes of Q and K: the score and PV products then run as three
                                                   // fp16 MFMA products each (the probabilities are split hi / lo in registers)
+  int vt_frag = 0;  // Q / K / V^T planes are fragment-major (QkvArgs::vt_frag); the fused launch only
 };
 hipError_t launch_attention(const AttnArgs& a, int np, hipStream_t st);
 

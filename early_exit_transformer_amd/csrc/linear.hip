@@ -170,11 +170,13 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
   [[maybe_unused]] h8 qfl[MT][KSQ];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const size_t qoff = ((size_t)bh * a.Tp + q0 + mt * 32 + r) * DH + 8 * hh;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
-      qf[mt][ks] = *(const h8*)(a.q + qoff + ks * 16);
-      if constexpr (X3) qfl[mt][ks] = *(const h8*)(a.q_lo + qoff + ks * 16);
+      // fragment-major planes (a.vt_frag, head dim 32: [b][h][32-frame block][k-step][lane][8]): 1 KiB contiguous per fragment
+      const size_t qoff = a.vt_frag ? (size_t)bh * a.Tp * DH + ((size_t)(((q0 >> 5) + mt) * 2 + ks) * 64 + lane) * 8
+                                    : ((size_t)bh * a.Tp + q0 + mt * 32 + r) * DH + 8 * hh + ks * 16;
+      qf[mt][ks] = *(const h8*)(a.q + qoff);
+      if constexpr (X3) qfl[mt][ks] = *(const h8*)(a.q_lo + qoff);
     }
   }
   f32x16 o[MT][DT];
@@ -205,14 +207,16 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
       const int kt = min(kt0 + j, last);
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks) {
-        f.k[j][ks] = *(const h8*)(kbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
-        if constexpr (X3) f.kl[j][ks] = *(const h8*)(klbase + ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh);
+        const size_t koff = a.vt_frag ? ((size_t)(kt * 2 + ks) * 64 + lane) * 8 : ((size_t)kt * 32 + r) * DH + ks * 16 + 8 * hh;
+        f.k[j][ks] = *(const h8*)(kbase + koff);
+        if constexpr (X3) f.kl[j][ks] = *(const h8*)(klbase + koff);
       }
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          const size_t off = (size_t)(dt * 32 + r) * a.Tp + kt * 32 + ks * 16 + 8 * hh;
+          // fragment-major planes (a.vt_frag; head dim 32): the fragment is 1 KiB contiguous in lane order
+          const size_t off = a.vt_frag ? ((size_t)(kt * 2 + ks) * 64 + lane) * 8 : (size_t)(dt * 32 + r) * a.Tp + kt * 32 + ks * 16 + 8 * hh;
           f.v[j][dt][ks] = *(const h8*)(vbase + off);
           f.vl[j][dt][ks] = v2 ? *(const h8*)(vlbase + off) : zero8;
         }
