@@ -86,6 +86,13 @@ def compare_grads(got, want, tol, label):
     # the benchmark's frame count (T' = 256: two query / key blocks of the fused attention per head, eight key tiles, ragged keys)
     (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 700]),
     (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=1, d_feed_forward=128), 2, 1027, [1027, 513]),
+    # the fused feed-forward launches (d_model 256 / 512, csrc/ffn.hip TR variants) at their edges: d_ff below one 128-wide chunk (three
+    # 32-wide tiles: one producer wave idles), a 32-wide rest after full chunks, the reference's d_ff, row counts that are no multiple of
+    # the 64- / 32-row tile (M = 3 x 32 = 96 and 2 x 37 = 74), a single short utterance (M = 12)
+    (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=96), 3, 131, [131, 100, 57]),
+    (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=416), 2, 151, [151, 90]),
+    (dict(n_enc_exits=1, n_enc_layers=1, d_feed_forward=2048), 1, 51, [51]),
+    (dict(d_model=512, n_head=8, n_enc_exits=1, n_enc_layers=1, d_feed_forward=160), 2, 151, [151, 120]),
 ])
 def test_training_step_matches_oracle_autograd(cfg, B, T, lens):
     kw = base_kwargs(**cfg)
