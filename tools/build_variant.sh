@@ -1,8 +1,9 @@
 #!/bin/bash
 # build_variant.sh <name> "<defines>" <file.hip> [file.hip ...]
 # Recompiles the named sources with extra -D flags and links libeec_<name>.so against the base objects
-# (tuning experiments; bench them with tools/ab_variants.py).  ffn.hip is built with -DEEC_CHAIN_MINIMAL (only the three
-# chain-kernel variants of the default f16f8 production plan, d_model 256) unless EEC_FULL=1.
+# (tuning experiments; bench them with tools/ab_variants.py / tools/ab_train.py).  ffn.hip is built with -DEEC_CHAIN_MINIMAL (only the
+# three chain-kernel variants of the production plan in the default f16x3 mode, d_model 256; add -DEEC_CHAIN_MINIMAL_F8 to the defines for
+# the f16f8 plan) unless EEC_FULL=1.  The d_model 512 and the training objects (ffn512 / ffn_train / ffn_train_bwd) are linked as built.
 set -e
 name=$1; defs=$2; shift 2
 cd "$(dirname "$0")/../early_exit_transformer_amd/csrc"
