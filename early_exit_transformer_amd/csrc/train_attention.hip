@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
   const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
+  const float scale2 = scale * 1.4426950408889634f;  // scores in the exp2 domain; the row log-sum-exp is kept in log2 units
   Frag qf[KSQ];
 #pragma unroll
   for (int ks = 0; ks < KSQ; ++ks) qf[ks] = load_kc<NP>(g.q + (long)q * g.ld + ks * 16 + 8 * hh, q < Tq);
@@ -224,15 +225,17 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
     f32x16 sc = zero16();
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) sc = mfma3<NP>(row_frag<DH, NP, true, false>(kt_t, r, ks, hh), qf[ks], sc);
+    // the softmax runs in the exp2 domain (scale2 = scale * log2 e: one v_exp_f32 per score, no multiply in front of it) and a key tile
+    // that lies inside the utterance -- all but the last one -- takes the form without the per-element key tests
+    const bool full = kt * 32 + 32 <= g.len;  // uniform
     float tmax = kNegBig;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int key = kt * 32 + acc_row(i, hh);
-      sc[i] = key < g.len ? sc[i] * scale : kNegBig;
+      sc[i] = (full || kt * 32 + acc_row(i, hh) < g.len) ? sc[i] * scale2 : kNegBig;
       tmax = fmaxf(tmax, sc[i]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax), alpha = __expf(m_run - m_new);
+    const float m_new = fmaxf(m_run, tmax), alpha = __builtin_amdgcn_exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.0f;
     f32x16 pd;
@@ -242,8 +245,8 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
       ds.mul4((uint64_t)(g.pbase + (long)q * Tq + kt * 32 + 8 * gk + 4 * hh), dm);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = 4 * gk + e, key = kt * 32 + acc_row(i, hh);
-        const float p = key < g.len ? __expf(sc[i] - m_new) : 0.0f;
+        const int i = 4 * gk + e;
+        const float p = (full || kt * 32 + acc_row(i, hh) < g.len) ? __builtin_amdgcn_exp2f(sc[i] - m_new) : 0.0f;
         psum += p;
         pd[i] = p * dm[e];
       }
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_fwd_kernel(const f
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq)
         *(f32x4*)(dst + dt * 32 + 8 * gq + 4 * hh) = (f32x4){o[dt][4 * gq] * inv, o[dt][4 * gq + 1] * inv, o[dt][4 * gq + 2] * inv, o[dt][4 * gq + 3] * inv};
-    if (hh == 0) lse[(long)z * Tq + q] = g.len > 0 ? m_run + __logf(l_tot) : NAN;
+    if (hh == 0) lse[(long)z * Tq + q] = g.len > 0 ? m_run + __builtin_amdgcn_logf(l_tot) : NAN;  // log2 of the row sum of exp2(scale2 * s): what the backward subtracts
   }
 }
 
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
   const int z = blockIdx.y, q = blockIdx.x * 128 + w * 32 + r;
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
+  const float scale2 = scale * 1.4426950408889634f;  // scores in the exp2 domain; the row log-sum-exp is kept in log2 units
   const float* dob = d_o + (long)(z / H) * Tq * D + (z % H) * DH;
   Frag qf[KSQ], dof[KSQ];
 #pragma unroll
@@ -326,7 +330,8 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
     qf[ks] = load_kc<NP>(g.q + (long)q * g.ld + ks * 16 + 8 * hh, q < Tq);
     dof[ks] = load_kc<NP>(dob + (long)q * D + ks * 16 + 8 * hh, q < Tq);
   }
-  const float lse_q = q < Tq ? lse[(long)z * Tq + q] : 0.0f, del_q = q < Tq ? delta[(long)z * Tq + q] : 0.0f;
+  // (a frame past the end: a log-sum-exp of +1e30 makes every one of its probabilities exp2(-1e30) = 0 without a per-element test)
+  const float lse_q = q < Tq ? lse[(long)z * Tq + q] : 1.0e30f, del_q = q < Tq ? delta[(long)z * Tq + q] : 0.0f;
   f32x16 dq[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) dq[dt] = zero16();
@@ -353,14 +358,15 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dq_kernel(cons
       dp = mfma3<NP>(row_frag<DH, NP, true, false>(vt_t, r, ks, hh), dof[ks], dp);
     }
     f32x16 dsv;
+    const bool full = kt * 32 + 32 <= g.len;  // uniform: only the utterance's last key tile tests its keys
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
       float dm[4];
       ds.mul4((uint64_t)(g.pbase + (long)q * Tq + kt * 32 + 8 * gk + 4 * hh), dm);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = 4 * gk + e, key = kt * 32 + acc_row(i, hh);
-        const float p = (key < g.len && q < Tq) ? __expf(sc[i] * scale - lse_q) : 0.0f;
+        const int i = 4 * gk + e;
+        const float p = (full || kt * 32 + acc_row(i, hh) < g.len) ? __builtin_amdgcn_exp2f(sc[i] * scale2 - lse_q) : 0.0f;
         dsv[i] = scale * p * (dp[i] * dm[e] - del_q);
       }
     }
@@ -404,6 +410,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(con
   const int z = blockIdx.y, key = blockIdx.x * 128 + w * 32 + r;  // the key this lane owns as an accumulator COLUMN
   const AttnGeoK g = attn_geo(qkv, key_len, H, Tq, D, DH, z);
   const DropState2 ds(drop);
+  const float scale2 = scale * 1.4426950408889634f;  // scores in the exp2 domain; the row log-sum-exp is kept in log2 units
   const float* dob = d_o + (long)(z / H) * Tq * D + (z % H) * DH;
   Frag kf[KSQ], vf[KSQ];
 #pragma unroll
@@ -452,7 +459,7 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(con
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool in = qt * 32 + 8 * gq + 4 * hh + e < Tq;
-          lse_r[4 * gq + e] = in ? lse[o4 + e] : 0.0f, del_r[4 * gq + e] = in ? delta[o4 + e] : 0.0f;
+          lse_r[4 * gq + e] = in ? lse[o4 + e] : 1.0e30f, del_r[4 * gq + e] = in ? delta[o4 + e] : 0.0f;  // past the end: p = exp2(-1e30) = 0
         }
       }
     }
@@ -463,9 +470,8 @@ __global__ __launch_bounds__(256, DH == 32 ? 2 : 1) void attn_bwd_dkv_kernel(con
       ds.mul4s((uint64_t)(g.pbase + (long)(qt * 32 + 8 * gq + 4 * hh) * Tq + key), (uint32_t)Tq, dm);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const int i = 4 * gq + e, q = qt * 32 + acc_row(i, hh);
-        const bool ok = live && q < Tq;
-        const float p = ok ? __expf(sc[i] * scale - lse_r[i]) : 0.0f;
+        const int i = 4 * gq + e;
+        const float p = live ? __builtin_amdgcn_exp2f(sc[i] * scale2 - lse_r[i]) : 0.0f;  // rows past the end carry lse = 1e30
         pdv[i] = p * dm[e];
         dsv[i] = scale * p * (dp[i] * dm[e] - del_r[i]);
       }
