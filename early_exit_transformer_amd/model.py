@@ -1070,15 +1070,23 @@ class _EncoderTrainFn(torch.autograd.Function):
             n = B * Tq
             li = 0
             with torch.no_grad():
+                # one multi-tensor update per momentum value (12 layers x 6 tiny kernels otherwise): lists of (layer index, module)
+                by_m = {}
                 for grp in model.conformer:
                     for layer in grp.conformer_layers:
                         bnm = layer.conv_module.sequential[3]
                         if bnm.track_running_stats and bnm.running_mean is not None:
-                            m = bnm.momentum if bnm.momentum is not None else 0.1
-                            bnm.running_mean.mul_(1 - m).add_(bn[li, 0], alpha=m)
-                            bnm.running_var.mul_(1 - m).add_(bn[li, 1] * (n / max(n - 1, 1)), alpha=m)
-                            bnm.num_batches_tracked += 1
+                            by_m.setdefault(bnm.momentum if bnm.momentum is not None else 0.1, []).append((li, bnm))
                         li += 1
+                if by_m:
+                    bvar = bn[:, 1] * (n / max(n - 1, 1))  # unbiased, as nn.BatchNorm1d stores it
+                    for m, mods in by_m.items():
+                        means, vars_ = [b_.running_mean for _, b_ in mods], [b_.running_var for _, b_ in mods]
+                        torch._foreach_mul_(means, 1 - m)
+                        torch._foreach_add_(means, [bn[i, 0] for i, _ in mods], alpha=m)
+                        torch._foreach_mul_(vars_, 1 - m)
+                        torch._foreach_add_(vars_, [bvar[i] for i, _ in mods], alpha=m)
+                        torch._foreach_add_([b_.num_batches_tracked for _, b_ in mods], 1)
         ctx.model, ctx.names, ctx.ws, ctx.ws_ptr, ctx.nbytes = model, names, ws, ws_ptr, nbytes
         ctx.keep = (src, len_dev)
         ctx.want_taps = bool(want_taps)
