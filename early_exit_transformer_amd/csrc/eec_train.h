@@ -46,6 +46,7 @@ struct GemmArgs {
   // set by launch_gemm: the output (and aux / old C read by the epilogue) is a large single-use tensor -- stores and those loads carry
   // the non-temporal hint, so that they do not push the operand tiles out of the L2 (EEC_TRAIN_NT_MB: threshold, 0 = never)
   int stream_out;
+  int stream_a, stream_b;  // ... and which operand, if any, is loaded with the hint (EEC_TRAIN_NT_IN_MB, default 64)
 };
 inline GemmArgs gemm_args(const float* A, long a_m, long a_k, const float* B, long b_n, long b_k, float* C, long c_m, int M, int N, int K) {
   GemmArgs g{};

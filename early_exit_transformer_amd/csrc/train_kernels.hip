@@ -79,6 +79,7 @@ struct TileLoader {
   int nv[R / 32];  // KC: 4 if the row exists else 0; transposed: how many of the thread's 4 rows exist
   long kstep;      // elements between consecutive k
   bool vec;        // every 4-element group is 16-byte aligned
+  bool nt = false; // the operand is a large tensor read once by this launch: loads carry the non-temporal hint (GemmArgs::stream_a / _b)
   bool clean;      // vec, and no 4-row group of a transposed operand straddles the last row
   __device__ __forceinline__ void init(const float* __restrict__ X, long s_r, long s_k, int r0, int Rmax, int tid) {
     kstep = KC ? 1 : s_k;
@@ -107,7 +108,7 @@ struct TileLoader {
     const float* __restrict__ b = x0 + (long)k0 * kstep;
 #pragma unroll
     for (int it = 0; it < R / 32; ++it) {
-      const f32x4 v = *(const f32x4*)(b + off[it]);
+      const f32x4 v = nt ? __builtin_nontemporal_load((const f32x4*)(b + off[it])) : *(const f32x4*)(b + off[it]);
       reg[it][0] = v[0], reg[it][1] = v[1], reg[it][2] = v[2], reg[it][3] = v[3];
     }
   }
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256, STAGES == 1 ? 3 : 2) void gemm_kernel(GemmArgs
   TileLoader<BN, BKC> lb;
   la.init(A, a_r, a_s, m0, g.M, tid);
   lb.init(B, b_r, b_s, n0, g.N, tid);
+  la.nt = g.stream_a != 0, lb.nt = g.stream_b != 0;
   // k-tiles are walked in a rotated order that differs between neighbouring workgroups: with power-of-two leading
   // dimensions the rows of a k-contiguous tile all fall on the same few L2 / HBM channels for a given k offset, and
   // workgroups in lockstep would all hit those at once (measured: 101 -> TFLOP/s class of the transposed layouts)
@@ -812,6 +814,14 @@ hipError_t launch_gemm(const GemmArgs& g_in, int np, hipStream_t st) {
   if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.nz <= 0) return hipSuccess;
   static const long nt_bytes = [] { const char* e = getenv("EEC_TRAIN_NT_MB"); return (e ? atol(e) : 32L) << 20; }();
   g.stream_out = nt_bytes > 0 && g.nz == 1 && (long)g.M * g.N * 4 >= nt_bytes;
+  // an operand of >= EEC_TRAIN_NT_IN_MB (default 64; 0 = never) that the launch reads once -- the [M, F] operand of a feed-forward weight
+  // gradient against the [M, D] one its 16 column tiles share -- is loaded with the non-temporal hint (same-box A/B of the step: -0.5 %)
+  static const long nt_in = [] { const char* e = getenv("EEC_TRAIN_NT_IN_MB"); return (e ? atol(e) : 64L) << 20; }();
+  if (nt_in > 0) {
+    const long ktot = g.ktot > 0 ? g.ktot : g.K;
+    g.stream_a = (long)g.M * ktot * 4 >= nt_in && (long)g.N * ktot * 4 < nt_in;
+    g.stream_b = (long)g.N * ktot * 4 >= nt_in && (long)g.M * ktot * 4 < nt_in;
+  }
   if ((g.a_m != 1 && g.a_k != 1) || (g.b_n != 1 && g.b_k != 1)) return hipErrorInvalidValue;
   if (g.epi != EPI_NONE && (g.nz != 1 || g.accumulate)) return hipErrorInvalidValue;  // the epilogues index C as one [M][N] matrix
   if (g.rowsum && (g.a_m != 1 || g.zdiv != 1)) return hipErrorInvalidValue;             // row sums: A row-contiguous, batch = splits
