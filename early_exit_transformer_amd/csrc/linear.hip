@@ -156,6 +156,9 @@ constexpr int kProjGluLds = 2 * Geo<D>::kAPlane + Geo<D>::kETile;  // 134144 / 1
 // so both products run as three fp16 MFMA products like every GEMM of the mode (what attn_kernel<.., 3, true> does in its own
 // launch, with K and its residual staged in LDS).  The second fragment set costs the registers of one key tile: blocks of 32 keys
 // instead of 64.
+#ifndef EEC_ATTN_LAZY
+#define EEC_ATTN_LAZY 0  // experiment (8 measured: 42.4 -> 42.2 us, not adopted): log2 units a block maximum may exceed the running maximum before the accumulators are rescaled (0: every block)
+#endif
 template <int D, int NP, bool X3 = false>
 __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& a, int row0) {
   using G = Geo<D>;
@@ -258,9 +261,21 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
 #pragma unroll
         for (int i = 0; i < 16; ++i) tmax = fmaxf(tmax, sc[j][mt][i]);
       tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-      const float m_new = fmaxf(m_run[mt], tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_new);
-      m_run[mt] = m_new;
+      // Lazy running maximum: it moves (and the row sums and the O accumulators are rescaled) only when some row of the tile sees a score
+      // more than kLazyMax above it -- a wave-uniform test; otherwise the block's probabilities are taken against the standing maximum
+      // (<= 2^kLazyMax: exact in the fp16 pair / fp32 sums all the same) and the exp2, the 16 DT + 1 multiplies per row tile are skipped.
+      const bool bump = EEC_ATTN_LAZY == 0 || __builtin_amdgcn_ballot_w64(tmax > m_run[mt] + (float)EEC_ATTN_LAZY) != 0;
+      if (bump) {
+        const float m_up = fmaxf(m_run[mt], tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[mt] - m_up);
+        m_run[mt] = m_up;
+        l_run[mt] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[mt][dt][i] *= alpha;
+      }
+      const float m_new = m_run[mt];
       float psum = 0.f;
       h8 pf[KB][2];
       [[maybe_unused]] h8 pfl[KB][2];
@@ -278,11 +293,9 @@ __device__ __forceinline__ void attn_tile_to_planes(char* smem, const AttnArgs& 
             pf[j][i >> 3][i & 7] = (half_t)p0, pf[j][i >> 3][(i & 7) + 1] = (half_t)p1;
           }
         }
-      l_run[mt] = l_run[mt] * alpha + psum;
+      l_run[mt] += psum;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[mt][dt][i] *= alpha;
 #pragma unroll
         for (int j = 0; j < KB; ++j)
 #pragma unroll
