@@ -141,6 +141,10 @@ struct ChainTrain {
   float p;                  // dropout probability (0: no dropout)
   unsigned long long seed;
   unsigned site_act, site_res;
+  // forward, optional: the LayerNorm that consumes the output rows next runs in the same row pass -- ln2 = LN(y; ln2_g, ln2_b) [M][D] with
+  // its statistics mean2 / rstd2 [M] (the attention module's LayerNorm after the first feed-forward, the layer's final one after the second)
+  const float *ln2_g = nullptr, *ln2_b = nullptr;
+  float *ln2 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
 };
 struct ChainArgs {
   float* x;  // [M][D] residual stream, updated in place

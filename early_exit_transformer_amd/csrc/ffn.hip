@@ -897,21 +897,34 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     } else if constexpr (TR == 1) {
       // y = x + res_scale * drop(W2 . h + b2): the row pass with the output dropout of the module, rows to a.tr.y
       const eect::DropState ds_res(eect::Drop{a.tr.p, a.tr.seed, a.tr.site_res});
+      RowV<G::kQ> v[RPW];
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
         const int row = row0 + w_e * RPW + i;
-        RowV<G::kQ> v = xr[i];
+        v[i] = xr[i];
 #pragma unroll
         for (int q = 0; q < G::kQ; ++q) {
           const float4 e = *(const float4*)(lds_e + (w_e * RPW + i) * G::kELd + (q * 256 + lane_e * 4) * 4);
           float m[4];
           ds_res.mul4((size_t)row * D + q * 256 + lane_e * 4, m);
-          v.p[q].x += res_scale * m[0] * e.x;
-          v.p[q].y += res_scale * m[1] * e.y;
-          v.p[q].z += res_scale * m[2] * e.z;
-          v.p[q].w += res_scale * m[3] * e.w;
+          v[i].p[q].x += res_scale * m[0] * e.x;
+          v[i].p[q].y += res_scale * m[1] * e.y;
+          v[i].p[q].z += res_scale * m[2] * e.z;
+          v[i].p[q].w += res_scale * m[3] * e.w;
         }
-        if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v, lane_e);
+        if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v[i], lane_e);
+      }
+      if (a.tr.ln2) {  // the LayerNorm that reads these rows next (the attention module's, or the layer's final one): rows and statistics
+        float mu[RPW], rs[RPW];
+        layer_norm_rows<D, RPW>(v, load_row<D>(a.tr.ln2_g, lane_e), load_row<D>(a.tr.ln2_b, lane_e), mu, rs);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int row = row0 + w_e * RPW + i;
+          if (row < M) {
+            store_row<D>(a.tr.ln2 + (size_t)row * D, v[i], lane_e);
+            if (lane_e == 0) a.tr.mean2[row] = mu[i], a.tr.rstd2[row] = rs[i];
+          }
+        }
       }
     } else if constexpr (more) {  // only stage 0 can have a successor
       chain_rowpass<D, NP, true>(smem, lds_e, x, xr, row0, M, res_scale, fin_g, fin_b, tap, a.st[1].ln_g, a.st[1].ln_b, lane_e, w_e);

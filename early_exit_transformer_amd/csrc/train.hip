@@ -227,7 +227,13 @@ void pack_ffn_module(Run& r, const FfnTape& t, const float* w1, const float* w2,
   for (int k = 0; k < 4; ++k) jb.out[0][k] = t.wp[k];
   RUN(eec::launch_pack_ffn_batch(jb, r.tr->cfg.d_ff, r.tr->cfg.d_model, kind0, 2, r.st));
 }
-float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2) {
+// LayerNorm rows + statistics that a feed-forward module's fused launch writes for whoever normalises its output next
+struct NextLn {
+  const float *g = nullptr, *b = nullptr;       // in: the parameters
+  float *ln = nullptr, *mean = nullptr, *rstd = nullptr;  // out: tape buffers, set (and filled) when the fused launch ran
+};
+float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_b, const float* w1, const float* b1, const float* w2, const float* b2,
+               NextLn* next = nullptr) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
   t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.pre = r.tape.f((size_t)M * F);
   t.act = r.tape.f((size_t)M * F);
@@ -242,6 +248,10 @@ float* ffn_fwd(Run& r, FfnTape& t, float* x, const float* ln_w, const float* ln_
     a.x = x, a.M = M, a.F = F, a.nstage = 1, a.D = D;
     a.st[0] = eec::FfnStage{ln_w, ln_b, t.wp[0], b1, t.wp[1], b2, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
     a.tr = eec::ChainTrain{y, t.ln, t.mean, t.rstd, t.pre, t.act, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    if (next) {  // the consumer's LayerNorm rides in this launch's row pass (saves a launch and a pass over the rows)
+      next->ln = r.tape.f((size_t)M * D), next->mean = r.tape.f(M), next->rstd = r.tape.f(M);
+      a.tr.ln2_g = next->g, a.tr.ln2_b = next->b, a.tr.ln2 = next->ln, a.tr.mean2 = next->mean, a.tr.rstd2 = next->rstd;
+    }
     RUN(eec::launch_ffn_train_fwd(a, r.tr->np, r.st));
     return y;
   }
@@ -274,12 +284,16 @@ void batched(GemmArgs& g, const AttnGeo& a, long az0, long az1, long bz0, long b
   g.a_z0 = az0, g.a_z1 = az1, g.b_z0 = bz0, g.b_z1 = bz1, g.c_z0 = cz0, g.c_z1 = cz1;
 }
 
-float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
+float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L, const NextLn* pre = nullptr) {
   const eec_trainer* tr = r.tr;
   const AttnGeo a = attn_geo(tr);
   const int M = tr->M, D = a.D, Tq = a.Tq;
   const bool fused = attn_fused_supported(D, a.H);  // a property of the configuration: the sizing pass carves the same way
-  t.x = x, t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M), t.qkv = r.tape.f((size_t)M * 3 * D);
+  const bool have_ln = pre && pre->ln;  // the module's LayerNorm already ran in the preceding feed-forward launch
+  t.x = x;
+  if (have_ln) t.ln = pre->ln, t.mean = pre->mean, t.rstd = pre->rstd;
+  else t.ln = r.tape.f((size_t)M * D), t.mean = r.tape.f(M), t.rstd = r.tape.f(M);
+  t.qkv = r.tape.f((size_t)M * 3 * D);
   t.ctx = r.tape.f((size_t)M * D);
   t.P = t.Pd = t.lse = nullptr;
   if (fused) {
@@ -290,7 +304,7 @@ float* attn_fwd(Run& r, AttnTape& t, float* x, const eec_layer_params& L) {
     t.Pd = tr->p > 0.0f ? pd : t.P;
   }
   t.site_p = r.site++, t.site_res = r.site++;
-  RUN(launch_ln_fwd(x, L.attn_ln_w, L.attn_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
+  if (!have_ln) RUN(launch_ln_fwd(x, L.attn_ln_w, L.attn_ln_b, t.ln, t.mean, t.rstd, M, D, r.st));
   linear_fwd(r, t.ln, L.attn_in_w, L.attn_in_b, t.qkv, M, 3 * D, D);
   r.scr.reset();
   if (fused) {
@@ -332,6 +346,27 @@ float* conv_fwd(Run& r, ConvTape& t, float* x, const eec_layer_params& L, float*
   return y;
 }
 
+// One Conformer layer (torchaudio ConformerLayer: ffn1, attention, conv module, ffn2, final LayerNorm).  When a feed-forward module runs
+// as the fused launch, the LayerNorm that reads its output next -- the attention module's, the layer's final one -- is computed in that
+// launch's row pass (ffn_fwd NextLn) instead of by its own kernel.
+float* layer_fwd(Run& r, LayerTape& t, float* x, const eec_layer_params& L, float* bn_mv_layer) {
+  const int M = r.tr->M, D = r.tr->cfg.d_model;
+  const bool fuse_ln = ffn_fused_fwd_supported(r.tr);
+  NextLn attn_ln{L.attn_ln_w, L.attn_ln_b}, fin_ln{L.final_ln_w, L.final_ln_b};
+  x = ffn_fwd(r, t.f1, x, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1, L.ffn1_b1, L.ffn1_w2, L.ffn1_b2, fuse_ln ? &attn_ln : nullptr);
+  x = attn_fwd(r, t.at, x, L, &attn_ln);
+  x = conv_fwd(r, t.cv, x, L, bn_mv_layer);
+  x = ffn_fwd(r, t.f2, x, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1, L.ffn2_b1, L.ffn2_w2, L.ffn2_b2, fuse_ln ? &fin_ln : nullptr);
+  t.x4 = x;
+  if (fin_ln.ln) {
+    t.out = fin_ln.ln, t.fmean = fin_ln.mean, t.frstd = fin_ln.rstd;
+  } else {
+    t.fmean = r.tape.f(M), t.frstd = r.tape.f(M), t.out = r.tape.f((size_t)M * D);
+    RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
+  }
+  return t.out;
+}
+
 void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengths, float* out, float* bn_mv, float* taps) {
   eec_trainer* tr = r.tr;
   const eec_config& c = tr->cfg;
@@ -358,13 +393,7 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
       const int li = e * c.layers_per_exit + l;
       const eec_layer_params& L = P->layers[li];
       LayerTape& t = tr->lt[li];
-      x = ffn_fwd(r, t.f1, x, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1, L.ffn1_b1, L.ffn1_w2, L.ffn1_b2);
-      x = attn_fwd(r, t.at, x, L);
-      x = conv_fwd(r, t.cv, x, L, bn_mv ? bn_mv + (size_t)li * 2 * D : nullptr);
-      x = ffn_fwd(r, t.f2, x, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1, L.ffn2_b1, L.ffn2_w2, L.ffn2_b2);
-      t.x4 = x, t.fmean = r.tape.f(M), t.frstd = r.tape.f(M), t.out = r.tape.f((size_t)M * D);
-      RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
-      x = t.out;
+      x = layer_fwd(r, t, x, L, bn_mv ? bn_mv + (size_t)li * 2 * D : nullptr);
     }
     if (taps) RUN(hipMemcpyAsync(taps + (size_t)e * M * D, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
     r.scr.reset();
@@ -728,13 +757,7 @@ void group_forward(Run& r, const eec_layer_params* layers, int n_layers, const f
   for (int l = 0; l < n_layers; ++l) {
     const eec_layer_params& L = layers ? layers[l] : kNone;
     LayerTape& t = tr->lt[l];
-    x = ffn_fwd(r, t.f1, x, L.ffn1_ln_w, L.ffn1_ln_b, L.ffn1_w1, L.ffn1_b1, L.ffn1_w2, L.ffn1_b2);
-    x = attn_fwd(r, t.at, x, L);
-    x = conv_fwd(r, t.cv, x, L, bn_mv ? bn_mv + (size_t)l * 2 * D : nullptr);
-    x = ffn_fwd(r, t.f2, x, L.ffn2_ln_w, L.ffn2_ln_b, L.ffn2_w1, L.ffn2_b1, L.ffn2_w2, L.ffn2_b2);
-    t.x4 = x, t.fmean = r.tape.f(M), t.frstd = r.tape.f(M), t.out = r.tape.f((size_t)M * D);
-    RUN(launch_ln_fwd(x, L.final_ln_w, L.final_ln_b, t.out, t.fmean, t.frstd, M, D, r.st));
-    x = t.out;
+    x = layer_fwd(r, t, x, L, bn_mv ? bn_mv + (size_t)l * 2 * D : nullptr);
   }
   if (x_out) RUN(hipMemcpyAsync(x_out, x, (size_t)M * D * sizeof(float), hipMemcpyDeviceToDevice, r.st));
 }
