@@ -145,6 +145,12 @@ struct ChainTrain {
   // its statistics mean2 / rstd2 [M] (the attention module's LayerNorm after the first feed-forward, the layer's final one after the second)
   const float *ln2_g = nullptr, *ln2_b = nullptr;
   float *ln2 = nullptr, *mean2 = nullptr, *rstd2 = nullptr;
+  // backward, optional: the module's own LayerNorm backward in the same row pass -- x_in = the module's input rows [M][D], mean / rstd
+  // their statistics (read), st[0].ln_g the LayerNorm weight; the launch's x (the gradient of the module's output) then becomes the
+  // gradient of the module's input IN PLACE (dx <- dx + LN'(d(LN(x)))), tr.y is not written, and ln_part [blocks][2][D] receives the
+  // per-workgroup column sums of the weight / bias gradient (blocks = the launch's grid)
+  const float* x_in = nullptr;
+  float* ln_part = nullptr;
 };
 struct ChainArgs {
   float* x;  // [M][D] residual stream, updated in place

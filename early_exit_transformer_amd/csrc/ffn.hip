@@ -885,14 +885,78 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
     const float res_scale = EEC_STAGE_FIELD(si, res_scale);
     const float *fin_g = EEC_STAGE_FIELD(si, fin_g), *fin_b = EEC_STAGE_FIELD(si, fin_b);
     float* tap = EEC_STAGE_FIELD(si, tap);
-    if constexpr (TR == 2) {  // d(LN(x)) rows, as they are
+    if constexpr (TR == 2) {
+      if (a.tr.x_in) {
+        // the module's LayerNorm backward in the same row pass (train_kernels.hip ln_bwd_kernel's arithmetic): with e = d(LN(x)),
+        // xh = (x - mean) rstd, t = e gamma:  dx <- dx + rstd (t - mean_c(t) - xh mean_c(t xh)),  dgamma += e xh,  dbeta += e
+        // (column sums over this workgroup's rows -> a.tr.ln_part[block][2][D], summed by the host's reduce launch)
+        constexpr int Q = G::kQ;
+        const RowV<Q> gam = load_row<D>(a.st[0].ln_g, lane_e);
+        RowV<Q> e[RPW], xh[RPW], dres[RPW];
+        float rsd[RPW], c1[RPW], c2[RPW];
+        RowV<Q> dgs = zero_row<Q>(), dbs = zero_row<Q>();
 #pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int row = row0 + w_e * RPW + i;
-        RowV<G::kQ> v;
+        for (int i = 0; i < RPW; ++i) {
+          const int rl = w_e * RPW + i, row = row0 + rl;
+          const bool ok = row < M;
+          const float mu = ok ? a.tr.mean[row] : 0.0f;
+          rsd[i] = ok ? a.tr.rstd[row] : 0.0f;
+          xh[i] = ok ? load_row<D>(a.tr.x_in + (size_t)row * D, lane_e) : zero_row<Q>();
+          dres[i] = ok ? load_row<D>(x + (size_t)row * D, lane_e) : zero_row<Q>();
+          c1[i] = 0.0f, c2[i] = 0.0f;
 #pragma unroll
-        for (int q = 0; q < G::kQ; ++q) v.p[q] = *(const float4*)(lds_e + (w_e * RPW + i) * G::kELd + (q * 256 + lane_e * 4) * 4);
-        if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v, lane_e);
+          for (int q = 0; q < Q; ++q) {
+            e[i].p[q] = *(const float4*)(lds_e + rl * G::kELd + (q * 256 + lane_e * 4) * 4);
+            float4& h = xh[i].p[q];
+            h.x = (h.x - mu) * rsd[i], h.y = (h.y - mu) * rsd[i], h.z = (h.z - mu) * rsd[i], h.w = (h.w - mu) * rsd[i];
+            const float4 ev = e[i].p[q], gq = gam.p[q];
+            const float tx = ev.x * gq.x, ty = ev.y * gq.y, tz = ev.z * gq.z, tw = ev.w * gq.w;
+            c1[i] += tx + ty + tz + tw;
+            c2[i] += tx * h.x + ty * h.y + tz * h.z + tw * h.w;
+            dgs.p[q].x += ev.x * h.x, dgs.p[q].y += ev.y * h.y, dgs.p[q].z += ev.z * h.z, dgs.p[q].w += ev.w * h.w;
+            dbs.p[q].x += ev.x, dbs.p[q].y += ev.y, dbs.p[q].z += ev.z, dbs.p[q].w += ev.w;
+          }
+        }
+        wave_sum_n<RPW>(c1);
+        wave_sum_n<RPW>(c2);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int row = row0 + w_e * RPW + i;
+          const float m1 = c1[i] * (1.0f / D), m2 = c2[i] * (1.0f / D);
+          RowV<Q> o;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float4 ev = e[i].p[q], gq = gam.p[q], h = xh[i].p[q], dr = dres[i].p[q];
+            o.p[q].x = rsd[i] * (ev.x * gq.x - m1 - h.x * m2) + dr.x;
+            o.p[q].y = rsd[i] * (ev.y * gq.y - m1 - h.y * m2) + dr.y;
+            o.p[q].z = rsd[i] * (ev.z * gq.z - m1 - h.z * m2) + dr.z;
+            o.p[q].w = rsd[i] * (ev.w * gq.w - m1 - h.w * m2) + dr.w;
+          }
+          if (row < M) store_row<D>(x + (size_t)row * D, o, lane_e);
+        }
+        // column sums of the tile: per wave in LDS (over the activation planes, dead since the chunk loops), then 2 D threads add the 8 waves
+        float* red = (float*)smem;  // [8 waves][2][D]
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          *(float4*)(red + (w_e * 2 + 0) * D + q * 256 + lane_e * 4) = dgs.p[q];
+          *(float4*)(red + (w_e * 2 + 1) * D + q * 256 + lane_e * 4) = dbs.p[q];
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * D; c += kFfnThreads) {
+          float t = 0.0f;
+#pragma unroll
+          for (int ww = 0; ww < 8; ++ww) t += red[ww * 2 * D + c];
+          a.tr.ln_part[(size_t)blockIdx.x * 2 * D + c] = t;
+        }
+      } else {  // d(LN(x)) rows, as they are
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int row = row0 + w_e * RPW + i;
+          RowV<G::kQ> v;
+#pragma unroll
+          for (int q = 0; q < G::kQ; ++q) v.p[q] = *(const float4*)(lds_e + (w_e * RPW + i) * G::kELd + (q * 256 + lane_e * 4) * 4);
+          if (row < M) store_row<D>(a.tr.y + (size_t)row * D, v, lane_e);
+        }
       }
     } else if constexpr (TR == 1) {
       // y = x + res_scale * drop(W2 . h + b2): the row pass with the output dropout of the module, rows to a.tr.y
@@ -982,7 +1046,8 @@ static hipError_t launch_chain_t(const ChainArgs& a, hipStream_t st) {
 // Fourth object of this source (build/ffn_train_bwd.o, bf16 operands): the training step's backward variants.
 hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st) {
   if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
-  if (!a.tr.y || !a.tr.pre || !a.tr.act || !a.tr.ln) return hipErrorInvalidValue;
+  if (!a.tr.pre || !a.tr.act || !a.tr.ln) return hipErrorInvalidValue;
+  if (a.tr.x_in ? (!a.tr.mean || !a.tr.rstd || !a.tr.ln_part || !a.st[0].ln_g) : !a.tr.y) return hipErrorInvalidValue;
   if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 2>(a, st);
   if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 2>(a, st);
   return hipErrorInvalidValue;

@@ -418,11 +418,17 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
     eec::ChainArgs a{};
     a.x = dx, a.M = M, a.F = F, a.nstage = 1, a.D = D;
     a.st[0] = eec::FfnStage{nullptr, nullptr, t.wp[2], nullptr, t.wp[3], nullptr, nullptr, nullptr, nullptr, nullptr, 0.5f, nullptr};
-    a.tr = eec::ChainTrain{dln, dh, nullptr, nullptr, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    // ... and the module's LayerNorm backward in the launch's row pass: dx becomes the gradient of the module's input in place, the
+    // weight / bias gradient leaves as per-workgroup column sums for the usual reduce launch
+    const int nb = (M + (D == 256 ? 64 : 32) - 1) / (D == 256 ? 64 : 32);  // the launch's grid: one workgroup per row tile
+    float* part = r.scr.f((size_t)nb * 2 * D);
+    a.st[0].ln_g = ln_w;
+    a.tr = eec::ChainTrain{nullptr, dh, t.mean, t.rstd, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
+    a.tr.x_in = t.x, a.tr.ln_part = part;
     RUN(eec::launch_ffn_train_bwd(a, r.tr->np, r.st));
+    RUN(launch_reduce_leading2(part, nb, D, g_ln_w, g_ln_b, r.st));
     linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
     linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
-    ln_bwd(r, dln, t.x, ln_w, t.mean, t.rstd, dx, true, g_ln_w, g_ln_b, M, D);
     return;
   }
   RUN(launch_scale_drop(dx, 0.5f, dh, (long)M * D, drop_of(r, t.site_res), r.st));
