@@ -151,6 +151,11 @@ struct ChainTrain {
   // per-workgroup column sums of the weight / bias gradient (blocks = the launch's grid)
   const float* x_in = nullptr;
   float* ln_part = nullptr;
+  // backward, optional: a LayerNorm backward IN FRONT of the module, in the prologue -- the launch's x rows are the gradient of that
+  // LayerNorm's output and are replaced in place by the gradient of its input (pl_x: the LayerNorm's input rows, pl_mean / pl_rstd its
+  // statistics, pl_g its weight); pl_part [8 x blocks][2][D]: one row of weight / bias gradient sums per wave
+  const float *pl_x = nullptr, *pl_mean = nullptr, *pl_rstd = nullptr, *pl_g = nullptr;
+  float* pl_part = nullptr;
 };
 struct ChainArgs {
   float* x;  // [M][D] residual stream, updated in place

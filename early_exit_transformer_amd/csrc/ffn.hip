@@ -464,6 +464,59 @@ __global__ __launch_bounds__(kFfnThreads, EEC_FFN_MINWAVES) void ffn_chain_kerne
       }
       __builtin_amdgcn_sched_barrier(0);
       start_streams(W0);
+      if (a.tr.pl_x) {
+        // A LayerNorm backward in front of the module (the layer-final LayerNorm when this is the second feed-forward module): the rows
+        // of x are the gradient of that LayerNorm's OUTPUT; they become -- in place, and for everything below -- the gradient of its
+        // input, LN'(g) = rstd (t - mean_c(t) - xh mean_c(t xh)) with t = g gamma, xh = (x_ln - mean) rstd.  The weight / bias gradient
+        // leaves as one partial row per WAVE (a.tr.pl_part[8 block + wave][2][D]: no LDS is free here), summed by the host's reduce launch.
+        constexpr int Q = G::kQ;
+        const RowV<Q> gam = load_row<D>(a.tr.pl_g, lane);
+        RowV<Q> xh[RPW];
+        float rsd[RPW], c1[RPW], c2[RPW];
+        RowV<Q> dgs = zero_row<Q>(), dbs = zero_row<Q>();
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int row = row0 + w * RPW + i;
+          const bool ok = row < M;
+          const float mu = ok ? a.tr.pl_mean[row] : 0.0f;
+          rsd[i] = ok ? a.tr.pl_rstd[row] : 0.0f;
+          xh[i] = ok ? load_row<D>(a.tr.pl_x + (size_t)row * D, lane) : zero_row<Q>();
+          c1[i] = 0.0f, c2[i] = 0.0f;
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            float4& h = xh[i].p[q];
+            h.x = (h.x - mu) * rsd[i], h.y = (h.y - mu) * rsd[i], h.z = (h.z - mu) * rsd[i], h.w = (h.w - mu) * rsd[i];
+            const float4 ev = v[i].p[q], gq = gam.p[q];
+            const float tx = ev.x * gq.x, ty = ev.y * gq.y, tz = ev.z * gq.z, tw = ev.w * gq.w;
+            c1[i] += tx + ty + tz + tw;
+            c2[i] += tx * h.x + ty * h.y + tz * h.z + tw * h.w;
+            dgs.p[q].x += ev.x * h.x, dgs.p[q].y += ev.y * h.y, dgs.p[q].z += ev.z * h.z, dgs.p[q].w += ev.w * h.w;
+            dbs.p[q].x += ev.x, dbs.p[q].y += ev.y, dbs.p[q].z += ev.z, dbs.p[q].w += ev.w;
+          }
+        }
+        wave_sum_n<RPW>(c1);
+        wave_sum_n<RPW>(c2);
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+          const int row = row0 + w * RPW + i;
+          const float m1 = c1[i] * (1.0f / D), m2 = c2[i] * (1.0f / D);
+#pragma unroll
+          for (int q = 0; q < Q; ++q) {
+            const float4 ev = v[i].p[q], gq = gam.p[q], h = xh[i].p[q];
+            v[i].p[q].x = rsd[i] * (ev.x * gq.x - m1 - h.x * m2);
+            v[i].p[q].y = rsd[i] * (ev.y * gq.y - m1 - h.y * m2);
+            v[i].p[q].z = rsd[i] * (ev.z * gq.z - m1 - h.z * m2);
+            v[i].p[q].w = rsd[i] * (ev.w * gq.w - m1 - h.w * m2);
+          }
+          if (row < M) store_row<D>(x + (size_t)row * D, v[i], lane);  // read again (by this same wave) as the residual gradient in the epilogue
+        }
+        float* pw = a.tr.pl_part + ((size_t)blockIdx.x * 8 + w) * 2 * D;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          *(float4*)(pw + q * 256 + lane * 4) = dgs.p[q];
+          *(float4*)(pw + D + q * 256 + lane * 4) = dbs.p[q];
+        }
+      }
 #pragma unroll
       for (int i = 0; i < RPW; ++i) {
         const int row = row0 + w * RPW + i;
@@ -1048,6 +1101,7 @@ hipError_t launch_ffn_train_bwd(const ChainArgs& a, int np, hipStream_t st) {
   if (a.nstage != 1 || a.F < 32 || a.F % 32 != 0 || (np != 1 && np != 3)) return hipErrorInvalidValue;
   if (!a.tr.pre || !a.tr.act || !a.tr.ln) return hipErrorInvalidValue;
   if (a.tr.x_in ? (!a.tr.mean || !a.tr.rstd || !a.tr.ln_part || !a.st[0].ln_g) : !a.tr.y) return hipErrorInvalidValue;
+  if (a.tr.pl_x && (!a.tr.pl_mean || !a.tr.pl_rstd || !a.tr.pl_g || !a.tr.pl_part)) return hipErrorInvalidValue;
   if (a.D == 256) return np == 3 ? launch_chain_t<256, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<256, 1, 2, 0, 0, 1, 2>(a, st);
   if (a.D == 512) return np == 3 ? launch_chain_t<512, 3, 2, 0, 0, 1, 2>(a, st) : launch_chain_t<512, 1, 2, 0, 0, 1, 2>(a, st);
   return hipErrorInvalidValue;

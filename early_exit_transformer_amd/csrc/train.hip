@@ -404,9 +404,17 @@ void forward(Run& r, const eec_params* P, const float* mel, const int64_t* lengt
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
+// a LayerNorm backward that sits in front of a feed-forward module's backward and has no residual path of its own (the layer-final
+// LayerNorm before the second module): dx holds the gradient of its output and receives the gradient of its input.  The fused launch does
+// it in its prologue; the GEMM path runs the LayerNorm-backward kernel first.
+struct PreLnBwd {
+  const float *x, *mean, *rstd, *g;
+  float *dg, *db;
+};
 void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float* w1, const float* w2, float* g_ln_w, float* g_ln_b, float* g_w1,
-             float* g_b1, float* g_w2, float* g_b2) {
+             float* g_b1, float* g_w2, float* g_b2, const PreLnBwd* pre = nullptr) {
   const int M = r.tr->M, D = r.tr->cfg.d_model, F = r.tr->cfg.d_ff;
+  if (pre && !ffn_fused_bwd_supported(r.tr)) ln_bwd(r, dx, pre->x, pre->g, pre->mean, pre->rstd, dx, false, pre->dg, pre->db, M, D);
   bwd_scratch_reset(r);
   float* dh = r.scr.f((size_t)M * D);
   float* dpre = r.scr.f((size_t)M * F);
@@ -425,7 +433,10 @@ void ffn_bwd(Run& r, const FfnTape& t, float* dx, const float* ln_w, const float
     a.st[0].ln_g = ln_w;
     a.tr = eec::ChainTrain{nullptr, dh, t.mean, t.rstd, t.pre, dpre, r.tr->p, (unsigned long long)r.tr->seed, t.site_act, t.site_res};
     a.tr.x_in = t.x, a.tr.ln_part = part;
+    float* ppart = pre ? r.scr.f((size_t)nb * 8 * 2 * D) : nullptr;
+    if (pre) a.tr.pl_x = pre->x, a.tr.pl_mean = pre->mean, a.tr.pl_rstd = pre->rstd, a.tr.pl_g = pre->g, a.tr.pl_part = ppart;
     RUN(eec::launch_ffn_train_bwd(a, r.tr->np, r.st));
+    if (pre) RUN(launch_reduce_leading2(ppart, nb * 8, D, pre->dg, pre->db, r.st));
     RUN(launch_reduce_leading2(part, nb, D, g_ln_w, g_ln_b, r.st));
     linear_bwd_weight(r, dh, t.act, g_w2, g_b2, M, D, F);
     linear_bwd_weight(r, dpre, t.ln, g_w1, g_b1, M, F, D);
@@ -543,9 +554,9 @@ void backward(Run& r, const eec_params* P, const eec_params* Gp, const float* ou
       const eec_layer_params& L = P->layers[li];
       eec_layer_params G = Gp->layers[li];
       const LayerTape& t = tr->lt[li];
-      ln_bwd(r, dx, t.x4, L.final_ln_w, t.fmean, t.frstd, dx, false, (float*)G.final_ln_w, (float*)G.final_ln_b, M, D);
+      const PreLnBwd fin{t.x4, t.fmean, t.frstd, L.final_ln_w, (float*)G.final_ln_w, (float*)G.final_ln_b};
       ffn_bwd(r, t.f2, dx, L.ffn2_ln_w, L.ffn2_w1, L.ffn2_w2, (float*)G.ffn2_ln_w, (float*)G.ffn2_ln_b, (float*)G.ffn2_w1, (float*)G.ffn2_b1,
-              (float*)G.ffn2_w2, (float*)G.ffn2_b2);
+              (float*)G.ffn2_w2, (float*)G.ffn2_b2, &fin);
       conv_bwd(r, t.cv, dx, L, G);
       attn_bwd(r, t.at, dx, L, G);
       ffn_bwd(r, t.f1, dx, L.ffn1_ln_w, L.ffn1_w1, L.ffn1_w2, (float*)G.ffn1_ln_w, (float*)G.ffn1_ln_b, (float*)G.ffn1_w1, (float*)G.ffn1_b1,
@@ -777,9 +788,9 @@ void group_backward(Run& r, const eec_layer_params* layers, const eec_layer_para
     const eec_layer_params& L = layers ? layers[l] : kNone;
     eec_layer_params G = grads ? grads[l] : kNone;
     const LayerTape& t = tr->lt[l];
-    ln_bwd(r, dx, t.x4, L.final_ln_w, t.fmean, t.frstd, dx, false, (float*)G.final_ln_w, (float*)G.final_ln_b, M, D);
+    const PreLnBwd fin{t.x4, t.fmean, t.frstd, L.final_ln_w, (float*)G.final_ln_w, (float*)G.final_ln_b};
     ffn_bwd(r, t.f2, dx, L.ffn2_ln_w, L.ffn2_w1, L.ffn2_w2, (float*)G.ffn2_ln_w, (float*)G.ffn2_ln_b, (float*)G.ffn2_w1, (float*)G.ffn2_b1,
-            (float*)G.ffn2_w2, (float*)G.ffn2_b2);
+            (float*)G.ffn2_w2, (float*)G.ffn2_b2, &fin);
     conv_bwd(r, t.cv, dx, L, G);
     attn_bwd(r, t.at, dx, L, G);
     ffn_bwd(r, t.f1, dx, L.ffn1_ln_w, L.ffn1_w1, L.ffn1_w2, (float*)G.ffn1_ln_w, (float*)G.ffn1_ln_b, (float*)G.ffn1_w1, (float*)G.ffn1_b1,
