@@ -331,7 +331,7 @@ class Early_conformer(_HipEncoderMixin, nn.Module):
         if src.dim() != 3 or src.size(1) != self._cfg.n_mels:
             raise ValueError(f"src must be [B, {self._cfg.n_mels}, T], got {tuple(src.shape)}")
         mine = ("conv_subsample.", "conformer.", self._head_attr + ".")
-        named = [(n, p) for n, p in self.named_parameters() if n.startswith(mine)]
+        named = [(n, p) for n, p in _named_tensors(self)[0] if n.startswith(mine)]
         names = tuple(n for n, _ in named)
         len_dev = _to_device(lengths, src.device)
         return _EncoderTrainFn.apply(self, src.contiguous().float(), len_dev, names, want_taps, *[p for _, p in named])
@@ -1022,6 +1022,31 @@ def _params_struct(model, tensors: Dict[str, Optional[Tensor]]):
     return st, (layers, hw, hb)
 
 
+def _named_tensors(model):
+    """(named parameters, state_dict entries) of ``model`` as lists of (name, tensor) -- the names and order of
+    ``named_parameters()`` / ``state_dict(keep_vars=True)`` -- from an index of (name, module, key) built once per model: the
+    training step asks twice per forward and the walk over ~400 modules was 1.7 ms of its host time.  The tensors are read from the
+    modules at every call (``.to()``, ``load_state_dict`` and in-place updates are seen); modules added later are not."""
+    idx = model.__dict__.get("_tensor_index")
+    if idx is None:
+        pidx, sidx, seen = [], [], set()
+        for mname, mod in model.named_modules(remove_duplicate=False):  # state_dict() lists a shared module under every path
+            pre = mname + "." if mname else ""
+            for k, v in mod._parameters.items():
+                if v is not None:
+                    sidx.append((pre + k, mod, k, True))
+                    if id(v) not in seen:  # named_parameters() lists a shared parameter once
+                        seen.add(id(v))
+                        pidx.append((pre + k, mod, k))
+            for k, v in mod._buffers.items():
+                if v is not None and k not in mod._non_persistent_buffers_set:
+                    sidx.append((pre + k, mod, k, False))
+        idx = model.__dict__["_tensor_index"] = (pidx, sidx)
+    pidx, sidx = idx
+    return ([(n, m._parameters[k]) for n, m, k in pidx],
+            [(n, (m._parameters if is_p else m._buffers)[k]) for n, m, k, is_p in sidx])
+
+
 class _EncoderTrainFn(torch.autograd.Function):
     """``Early_conformer.forward`` in train mode and its backward on the HIP training kernels (csrc/train.hip): what
     ``enc_out = model(batch_0, valid_lengths)`` / ``loss.backward()`` do in the reference's train.py:53-68.  BatchNorm uses
@@ -1044,7 +1069,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                 _trainer_check(lib.eec_trainer_create(C.byref(cfg), C.byref(h)), "eec_trainer_create")
                 model._trainer, model._trainer_device = h, dev
             tensors = dict(zip(names, params))
-            for k, v in model.state_dict(keep_vars=True).items():
+            for k, v in _named_tensors(model)[1]:  # what model.state_dict(keep_vars=True) holds, without walking the module tree again
                 tensors.setdefault(k, v)
             for k, t in tensors.items():
                 if t.is_floating_point() and (t.device != dev or t.dtype != torch.float32 or not t.is_contiguous()):

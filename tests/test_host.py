@@ -549,3 +549,21 @@ def test_beam_search_equals_the_reference_algorithm(min_length, max_length, beam
         assert hit_eos, "the EOS branch must be exercised when min_length allows it"
     if min_length >= max_length:
         assert not hit_eos
+
+
+def test_named_tensor_index_matches_the_module_tree_walks():
+    """model._named_tensors (the cached index the training forward uses) == named_parameters() / state_dict(keep_vars=True): names,
+    order and the very tensors -- also after .to() replaced them and after load_state_dict."""
+    from conftest import base_kwargs
+    from early_exit_transformer_amd.model import Early_conformer, full_conformer, _named_tensors
+    kw = base_kwargs(n_enc_exits=2, n_enc_layers=1, d_feed_forward=64)
+    fkw = {k: v for k, v in kw.items() if k != "src_pad_idx"}
+    for m in (Early_conformer(**kw), full_conformer(trg_pad_idx=126, n_dec_layers=1, **fkw)):
+        for _ in range(2):
+            a, b = _named_tensors(m)
+            want_p = list(m.named_parameters())
+            assert [n for n, _ in a] == [n for n, _ in want_p] and all(x is y for (_, x), (_, y) in zip(a, want_p))
+            sd = m.state_dict(keep_vars=True)
+            assert [n for n, _ in b] == list(sd.keys()) and all(t is sd[n] for n, t in b)
+            m = m.double().float()  # replaces every parameter's data and every buffer tensor
+            m.load_state_dict(m.state_dict())
